@@ -1,0 +1,99 @@
+// model.h -- the layer plan of one annotator model and its device state.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+typedef struct ncclComm* ncclComm_t;
+
+namespace dnnca {
+
+struct T {          // a tensor = data view + gradient view of identical geometry
+    View d, g;
+};
+
+inline T tslice(const T& t, int c0, int c) { return T{slice(t.d, c0, c), slice(t.g, c0, c)}; }
+
+enum OpType { OP_CONV = 0, OP_BN, OP_POOL, OP_TCONV, OP_HEAD };
+
+struct Op {
+    OpType type;
+    std::string name;
+    T inA, inB, out;
+    int64_t w_off = -1, b_off = -1;      // trainable offsets: kernel/bias, or gamma/beta for BN
+    int64_t mm_off = -1, mv_off = -1;    // state offsets (BN moving mean / variance)
+    float alpha = -1.f;                  // conv activation: <0 none, 0 relu, >0 leaky
+    int k = 0;                           // conv kernel size / pool+tconv rate
+    bool need_din = true;                // false for the convs that read the network input
+    bool accA = false, accB = false;     // backward: accumulate into (instead of overwrite) the input gradients
+    float* coef = nullptr;               // BN: [scale, shift, mean, inv] x C
+    double* ws = nullptr;                // BN: [sum, centred sumsq] x C
+};
+
+struct ParamInfo {
+    std::string name;
+    int64_t shape[4];
+    int ndim;
+    int trainable;
+    int64_t offset;
+    int64_t size;
+};
+
+struct KStat {
+    std::string name;
+    int64_t launches = 0;
+    double total_ms = 0, bytes = 0, flops = 0;
+};
+
+struct Model {
+    dnnca_model_desc desc;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<ParamInfo> params;
+    std::vector<Op> ops;
+    std::vector<void*> allocs;
+    int64_t nT = 0, nS = 0;
+    float *p = nullptr, *g = nullptr, *m = nullptr, *v = nullptr, *state = nullptr;
+    double* scalars = nullptr;           // kScalars doubles
+    float* out5 = nullptr;               // = g + nT : [loss, positive_rate, weight, ymin, ymax]
+    float *x_stage = nullptr, *y_stage = nullptr, *logits = nullptr, *dlogits = nullptr, *prob = nullptr;
+    float* thr_dev = nullptr;
+    double* conf_dev = nullptr;
+    T xin;                               // network input view (points at the current batch)
+    int outH = 0, outW = 0;
+    int64_t iterations = 0;
+    float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f;
+    int last_batch = 0;
+    // data parallel
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    // measurement
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int prof_mode = 0;
+    bool dry = false;
+    std::string focus, plan_text;
+    std::map<std::string, int> kid;
+    std::vector<KStat> kstats;
+    struct Rec {
+        int id;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> evpool;
+
+    ~Model();
+    int build();
+    int alloc(void** ptr, size_t bytes);
+    int forward(const float* x_dev, int B, bool training);
+    int loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cfg, bool backward);
+    int optimizer_step(float lr);
+    int flush_profile();
+
+    // launch accounting ------------------------------------------------------------------------------------
+    bool begin(const char* name, double bytes, double flops);
+    void end();
+};
+
+}  // namespace dnnca

@@ -1,0 +1,898 @@
+// model.hip -- plan builder (Keras build order of the reference's layers), step orchestration and the C ABI.
+//
+// Reference structure followed (annotator/models/tf_models): components.py:16-81 Downsample, :84-166 Upsample,
+// :169-247 Encoder, :250-320 Decoder; unet.py:19-88 UNet, :91-191 MulmoUNet, :194-300 annotators.
+#include "model.h"
+
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <cmath>
+
+#include "fast.h"
+#include "kernels.h"
+
+namespace dnnca {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+enum { kScalars = 8 };
+static constexpr float kBnMomentum = 0.99f;   // Keras BatchNormalization defaults [TF-2.6]
+static constexpr float kBnEps = 1e-3f;
+
+Model::~Model() {
+    for (void* a : allocs) (void)hipFree(a);
+    for (auto& r : recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : evpool) (void)hipEventDestroy(e);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (comm) ncclCommDestroy(comm);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+int Model::alloc(void** ptr, size_t bytes) {
+    if (bytes == 0) bytes = 4;
+    HIP_TRY(hipMalloc(ptr, bytes));
+    allocs.push_back(*ptr);
+    HIP_TRY(hipMemsetAsync(*ptr, 0, bytes, stream));
+    return DNNCA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- launch accounting
+bool Model::begin(const char* name, double bytes, double flops) {
+    if (dry) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\t%.0f\t%.0f\n", name, bytes, flops);
+        plan_text += line;
+        return false;
+    }
+    if (prof_mode == 0) return true;
+    if (prof_mode == 2 && focus != name) return true;
+    int id;
+    auto it = kid.find(name);
+    if (it == kid.end()) {
+        id = (int)kstats.size();
+        kid[name] = id;
+        KStat ks;
+        ks.name = name;
+        kstats.push_back(ks);
+    } else {
+        id = it->second;
+    }
+    KStat& ks = kstats[id];
+    ks.bytes += bytes;
+    ks.flops += flops;
+    ks.launches += 1;
+    Rec r;
+    r.id = id;
+    auto get = [&]() {
+        hipEvent_t e = nullptr;
+        if (!evpool.empty()) {
+            e = evpool.back();
+            evpool.pop_back();
+        } else {
+            (void)hipEventCreate(&e);
+        }
+        return e;
+    };
+    r.a = get();
+    r.b = get();
+    (void)hipEventRecord(r.a, stream);
+    recs.push_back(r);
+    return true;
+}
+
+void Model::end() {
+    if (dry || prof_mode == 0 || recs.empty()) return;
+    Rec& r = recs.back();
+    if (r.b && r.id >= 0) {
+        (void)hipEventRecord(r.b, stream);
+        r.id = -r.id - 1;   // mark closed
+    }
+}
+
+int Model::flush_profile() {
+    if (recs.empty()) return DNNCA_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (auto& r : recs) {
+        int id = r.id < 0 ? -r.id - 1 : r.id;
+        float ms = 0.f;
+        if (r.id < 0 && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) kstats[id].total_ms += ms;
+        evpool.push_back(r.a);
+        evpool.push_back(r.b);
+    }
+    recs.clear();
+    return DNNCA_OK;
+}
+
+// A launch is only "open" for profiling between begin() and end(); focus mode leaves other launches untouched.
+#define LAUNCH(m, name, bytes, flops, call)                \
+    do {                                                   \
+        bool prof_open_ = false;                           \
+        if ((m)->dry || (m)->prof_mode) {                  \
+            size_t before_ = (m)->recs.size();             \
+            bool go_ = (m)->begin(name, bytes, flops);     \
+            prof_open_ = (m)->recs.size() != before_;      \
+            if (!go_) break;                               \
+        }                                                  \
+        call;                                              \
+        if (prof_open_) (m)->end();                        \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------- plan
+int Model::build() {
+    const dnnca_model_desc& d = desc;
+    if (d.arch != DNNCA_ARCH_UNET && d.arch != DNNCA_ARCH_MULMO) { set_error("unknown arch %d", d.arch); return DNNCA_EINVAL; }
+    if (d.conv_stride != 1) { set_error("conv_stride %d unsupported (reference configs use 1)", d.conv_stride); return DNNCA_EINVAL; }
+    if (d.padding != DNNCA_PAD_SAME) { set_error("padding: valid is unsupported (every reference config uses same; labels could not match the cropped logits in utils/losses.py:34)"); return DNNCA_EINVAL; }
+    if (d.kernel_size < 1 || d.kernel_size % 2 == 0) { set_error("kernel_size %d must be odd", d.kernel_size); return DNNCA_EINVAL; }
+    if (d.in_channels < 1 || d.n_filters_first < 1 || d.n_downsample < 1 || d.rate < 2 || d.n_conv < 1 || d.max_batch < 1) { set_error("bad model_options"); return DNNCA_EINVAL; }
+    if (d.dtype != DNNCA_F32 && d.dtype != DNNCA_BF16) { set_error("unknown dtype"); return DNNCA_EINVAL; }
+    int div = 1;
+    for (int i = 0; i < d.n_downsample; ++i) div *= d.rate;
+    if (d.height % div || d.width % div) { set_error("H, W (%d, %d) must be divisible by rate^n_downsample = %d", d.height, d.width, div); return DNNCA_EINVAL; }
+    const bool mulmo = d.arch == DNNCA_ARCH_MULMO;
+    const int nenc = mulmo ? d.in_channels : 1;
+    if (mulmo && (d.reference_index < 0 || d.reference_index >= nenc)) { set_error("reference_index out of range"); return DNNCA_EINVAL; }
+    const int K = d.kernel_size, r = d.rate, L = d.n_downsample;
+    const size_t MB = (size_t)d.max_batch;
+    const float act = d.leaky_alpha;   // 0 relu, >0 leaky
+
+    auto add_param = [&](const std::string& name, std::initializer_list<int64_t> shape, int trainable) -> int64_t {
+        ParamInfo pi;
+        pi.name = name;
+        pi.ndim = (int)shape.size();
+        pi.size = 1;
+        int i = 0;
+        for (int k = 0; k < 4; ++k) pi.shape[k] = 1;
+        for (auto s : shape) {
+            pi.shape[i++] = s;
+            pi.size *= s;
+        }
+        pi.trainable = trainable;
+        int64_t& n = trainable ? nT : nS;
+        pi.offset = n;
+        n += pi.size;
+        params.push_back(pi);
+        return pi.offset;
+    };
+
+    std::vector<std::pair<float**, size_t>> pending;   // tensors to allocate: (slot, floats)
+    struct Slot { float* d; float* g; };
+    std::vector<Slot*> slots;
+    // tensors are allocated immediately (stream-ordered memset) -- simple and the sizes are static
+    int rc = DNNCA_OK;
+    auto new_tensor = [&](int H, int W, int C) -> T {
+        T t;
+        size_t n = MB * H * W * C;
+        float *dp = nullptr, *gp = nullptr;
+        if (rc == DNNCA_OK) rc = alloc((void**)&dp, n * 4);
+        if (rc == DNNCA_OK) rc = alloc((void**)&gp, n * 4);
+        t.d.p = dp; t.d.H = H; t.d.W = W; t.d.C = C; t.d.ps = C;
+        t.g = t.d;
+        t.g.p = gp;
+        return t;
+    };
+
+    auto add_bn = [&](const std::string& prefix, const T& in, const T& out) {
+        Op o;
+        o.type = OP_BN;
+        o.name = prefix;
+        o.inA = in;
+        o.out = out;
+        int C = in.d.C;
+        o.w_off = add_param(prefix + ".gamma", {C}, 1);
+        o.b_off = add_param(prefix + ".beta", {C}, 1);
+        o.mm_off = add_param(prefix + ".moving_mean", {C}, 0);
+        o.mv_off = add_param(prefix + ".moving_variance", {C}, 0);
+        if (rc == DNNCA_OK) rc = alloc((void**)&o.coef, (size_t)4 * C * 4);
+        if (rc == DNNCA_OK) rc = alloc((void**)&o.ws, (size_t)2 * C * 8);
+        ops.push_back(o);
+    };
+    auto add_conv = [&](const std::string& prefix, const T& inA, const T& inB, const T& out, bool need_din) {
+        Op o;
+        o.type = OP_CONV;
+        o.name = prefix;
+        o.inA = inA;
+        o.inB = inB;
+        o.out = out;
+        o.k = K;
+        o.alpha = act;
+        o.need_din = need_din;
+        o.w_off = add_param(prefix + ".kernel", {K, K, inA.d.C + inB.d.C, out.d.C}, 1);
+        o.b_off = add_param(prefix + ".bias", {out.d.C}, 1);
+        ops.push_back(o);
+    };
+
+    xin.d.H = d.height; xin.d.W = d.width; xin.d.C = d.in_channels; xin.d.ps = d.in_channels;
+    xin.g = xin.d;
+    std::vector<int> filters;
+    for (int i = 0, f = d.n_filters_first; i < L; ++i, f *= r) filters.push_back(f);
+
+    T empty;   // C = 0
+    std::vector<std::vector<T>> skips(nenc);
+    std::vector<T> bottoms(nenc);
+    int hb = d.height / div, wb = d.width / div;
+    T bottom_cat;
+    if (mulmo) bottom_cat = new_tensor(hb, wb, filters[L - 1] * nenc);
+    for (int e = 0; e < nenc; ++e) {
+        std::string enc = mulmo ? "encoder" + std::to_string(e) : "encoder";
+        T cur = mulmo ? tslice(xin, e, 1) : xin;
+        bool first = true;
+        int H = d.height, W = d.width;
+        for (int i = 0; i < L; ++i) {
+            std::string p = enc + ".down" + std::to_string(i);
+            int f = filters[i];
+            for (int j = 0; j < d.n_conv; ++j) {
+                T a = new_tensor(H, W, f);
+                add_conv(p + ".conv" + std::to_string(j), cur, empty, a, !first);
+                first = false;
+                cur = a;
+                if (d.bn) {
+                    T n = new_tensor(H, W, f);
+                    add_bn(p + ".bn" + std::to_string(j), cur, n);
+                    cur = n;
+                }
+            }
+            skips[e].push_back(cur);
+            H /= r;
+            W /= r;
+            bool last = (i == L - 1);
+            T dest = (mulmo && last) ? tslice(bottom_cat, e * f, f) : T();
+            T pooled = (d.bn || !(mulmo && last)) ? new_tensor(H, W, f) : dest;
+            Op o;
+            o.type = OP_POOL;
+            o.name = p + ".pool";
+            o.inA = cur;
+            o.out = pooled;
+            o.k = r;
+            ops.push_back(o);
+            cur = pooled;
+            if (d.bn) {
+                T n = (mulmo && last) ? dest : new_tensor(H, W, f);
+                add_bn(p + ".pool_bn", cur, n);
+                cur = n;
+            }
+        }
+        bottoms[e] = cur;
+    }
+    T cur = mulmo ? bottom_cat : bottoms[0];
+    const std::vector<T>& ref = skips[mulmo ? d.reference_index : 0];
+    for (int u = 0; u < L; ++u) {
+        int i = L - 1 - u;
+        int f = filters[i];
+        std::string p = "decoder.up" + std::to_string(u);
+        int H = cur.d.H * r, W = cur.d.W * r;
+        T t = new_tensor(H, W, f);
+        Op o;
+        o.type = OP_TCONV;
+        o.name = p + ".tconv";
+        o.inA = cur;
+        o.out = t;
+        o.k = r;
+        o.w_off = add_param(p + ".tconv.kernel", {r, r, f, cur.d.C}, 1);
+        o.b_off = add_param(p + ".tconv.bias", {f}, 1);
+        ops.push_back(o);
+        cur = t;
+        if (d.bn) {
+            T n = new_tensor(H, W, f);
+            add_bn(p + ".tconv_bn", cur, n);
+            cur = n;
+        }
+        T skip = ref[i];
+        for (int j = 0; j < d.n_conv; ++j) {
+            T a = new_tensor(H, W, f);
+            add_conv(p + ".conv" + std::to_string(j), cur, j == 0 ? skip : empty, a, true);
+            cur = a;
+            if (d.bn) {
+                T n = new_tensor(H, W, f);
+                add_bn(p + ".bn" + std::to_string(j), cur, n);
+                cur = n;
+            }
+        }
+    }
+    {
+        Op o;
+        o.type = OP_HEAD;
+        o.name = "head";
+        o.inA = cur;
+        o.w_off = add_param("head.kernel", {1, 1, cur.d.C, 1}, 1);
+        o.b_off = add_param("head.bias", {1}, 1);
+        ops.push_back(o);
+        outH = cur.d.H;
+        outW = cur.d.W;
+    }
+    if (rc != DNNCA_OK) return rc;
+
+    // backward accumulation flags: the first op (in backward order) to produce a gradient overwrites, later ones add.
+    std::map<float*, bool> written;
+    for (int i = (int)ops.size() - 1; i >= 0; --i) {
+        Op& o = ops[i];
+        if (!o.need_din) continue;
+        o.accA = written[o.inA.g.p];
+        written[o.inA.g.p] = true;
+        if (o.type == OP_CONV && o.inB.d.C) {
+            o.accB = written[o.inB.g.p];
+            written[o.inB.g.p] = true;
+        }
+    }
+
+    // flat buffers
+    DN_TRY(alloc((void**)&p, (size_t)nT * 4));
+    DN_TRY(alloc((void**)&g, (size_t)(nT + 8) * 4));
+    DN_TRY(alloc((void**)&m, (size_t)nT * 4));
+    DN_TRY(alloc((void**)&v, (size_t)nT * 4));
+    DN_TRY(alloc((void**)&state, (size_t)nS * 4));
+    DN_TRY(alloc((void**)&scalars, kScalars * 8));
+    out5 = g + nT;
+    size_t npix = MB * outH * outW;
+    DN_TRY(alloc((void**)&x_stage, MB * d.height * d.width * d.in_channels * 4));
+    DN_TRY(alloc((void**)&y_stage, npix * 4));
+    DN_TRY(alloc((void**)&logits, npix * 4));
+    DN_TRY(alloc((void**)&dlogits, npix * 4));
+    DN_TRY(alloc((void**)&prob, npix * 4));
+    DN_TRY(alloc((void**)&thr_dev, 256 * 4));
+    DN_TRY(alloc((void**)&conf_dev, 256 * 4 * 8));
+    // Keras defaults for the non-trainable / BN variables: gamma 1, moving_variance 1 (the rest 0)
+    {
+        std::vector<float> hp((size_t)nT, 0.f), hs((size_t)nS, 0.f);
+        for (auto& pi : params) {
+            bool one = pi.name.size() > 6 && (pi.name.rfind(".gamma") == pi.name.size() - 6 ||
+                                              pi.name.rfind(".moving_variance") == pi.name.size() - 16);
+            if (!one) continue;
+            float* dst = pi.trainable ? hp.data() : hs.data();
+            for (int64_t k = 0; k < pi.size; ++k) dst[pi.offset + k] = 1.f;
+        }
+        if (nT) HIP_TRY(hipMemcpyAsync(p, hp.data(), (size_t)nT * 4, hipMemcpyHostToDevice, stream));
+        if (nS) HIP_TRY(hipMemcpyAsync(state, hs.data(), (size_t)nS * 4, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    return DNNCA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+static inline double nelem(int B, const View& v) { return (double)B * v.H * v.W * v.C; }
+
+int Model::forward(const float* x_dev, int B, bool training) {
+    if (B < 1 || B > desc.max_batch) { set_error("batch %d outside [1, max_batch=%d]", B, desc.max_batch); return DNNCA_EINVAL; }
+    last_batch = B;
+    const bool generic = desc.flags & 1;
+    // input ops carry a channel offset relative to xin; rebase them on this batch
+    for (Op& o : ops)
+        if (o.type == OP_CONV && !o.need_din) {
+            ptrdiff_t off = o.inA.d.p - xin.d.p;
+            o.inA.d.p = const_cast<float*>(x_dev) + off;
+        }
+    xin.d.p = const_cast<float*>(x_dev);
+
+    for (Op& o : ops) {
+        switch (o.type) {
+            case OP_CONV: {
+                int Cin = o.inA.d.C + o.inB.d.C;
+                double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d) + nelem(B, o.out.d));
+                double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
+                if (!generic && fast_conv_fwd(this, B, o, bytes, flops)) break;
+                LAUNCH(this, "g_conv_fwd", bytes, flops,
+                       g_conv_fwd(stream, B, o.inA.d, o.inB.d, p + o.w_off, p + o.b_off, o.out.d, o.k, o.alpha));
+                break;
+            }
+            case OP_BN: {
+                int C = o.inA.d.C;
+                double n = (double)B * o.inA.d.H * o.inA.d.W;
+                double tb = 4.0 * nelem(B, o.inA.d);
+                if (training) {
+                    HIP_TRY(hipMemsetAsync(o.ws, 0, (size_t)2 * C * 8, stream));
+                    LAUNCH(this, "g_bn_stats_mean", tb, tb / 4, g_bn_stats_mean(stream, B, o.inA.d, o.ws));
+                    LAUNCH(this, "g_bn_stats_var", tb, tb / 2, g_bn_stats_var(stream, B, o.inA.d, o.ws));
+                }
+                LAUNCH(this, "g_bn_finalize", 0, 0,
+                       g_bn_finalize(stream, C, n, o.ws, p + o.w_off, p + o.b_off, state + o.mm_off, state + o.mv_off,
+                                     o.coef, training ? 1 : 0, kBnMomentum, kBnEps));
+                LAUNCH(this, "g_bn_apply", 2 * tb, tb / 2, g_bn_apply(stream, B, o.inA.d, o.out.d, o.coef));
+                break;
+            }
+            case OP_POOL: {
+                double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
+                if (!generic && fast_pool_fwd(this, B, o, bytes)) break;
+                LAUNCH(this, "g_pool_fwd", bytes, 0, g_pool_fwd(stream, B, o.inA.d, o.out.d, o.k));
+                break;
+            }
+            case OP_TCONV: {
+                double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
+                double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
+                if (!generic && fast_tconv_fwd(this, B, o, bytes, flops)) break;
+                LAUNCH(this, "g_tconv_fwd", bytes, flops,
+                       g_tconv_fwd(stream, B, o.inA.d, p + o.w_off, p + o.b_off, o.out.d, o.k));
+                break;
+            }
+            case OP_HEAD: {
+                double npix = (double)B * outH * outW;
+                LAUNCH(this, "g_head_fwd", 4.0 * (nelem(B, o.inA.d) + npix), 2.0 * nelem(B, o.inA.d),
+                       g_head_fwd(stream, B, o.inA.d, p + o.w_off, p + o.b_off, logits));
+                break;
+            }
+        }
+    }
+    return DNNCA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- loss + backward
+int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cfg, bool backward) {
+    const bool generic = desc.flags & 1;
+    size_t npix = (size_t)B * outH * outW;
+    // scalars: label sum 0, min +inf, max -inf, loss 0, l2 0
+    double init[kScalars] = {0.0, INFINITY, -INFINITY, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (!dry) HIP_TRY(hipMemcpyAsync(scalars, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    LAUNCH(this, "g_label_stats", 4.0 * npix, (double)npix, g_label_stats(stream, npix, y_dev, scalars));
+    // dlogits scale: mean over (H, W), then mean over the (rank-local) batch.  Under data parallel every rank uses its
+    // local mean; the cross-rank 1/world is applied to the all-reduced gradient in the optimizer step.
+    float gscale = (float)(1.0 / ((double)outH * outW * B));
+    LAUNCH(this, "g_loss", 4.0 * npix * (backward ? 4 : 3), 20.0 * npix,
+           g_loss(stream, npix, logits, y_dev, cfg, (double)npix, scalars, backward ? dlogits : nullptr, prob, gscale));
+    if (backward) {
+        if (!dry) HIP_TRY(hipMemsetAsync(g, 0, (size_t)(nT + 8) * 4, stream));
+        for (int i = (int)ops.size() - 1; i >= 0; --i) {
+            Op& o = ops[i];
+            switch (o.type) {
+                case OP_HEAD: {
+                    double fb = 4.0 * nelem(B, o.inA.d);
+                    LAUNCH(this, "g_head_bwd", 2 * fb + 4.0 * npix, 4.0 * nelem(B, o.inA.d),
+                           g_head_bwd(stream, B, o.inA.d, p + o.w_off, dlogits, o.inA.g, g + o.w_off, g + o.b_off));
+                    break;
+                }
+                case OP_CONV: {
+                    int Cin = o.inA.d.C + o.inB.d.C;
+                    double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d));
+                    double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
+                    if (!generic && fast_conv_bwd(this, B, o, ob, ib, flops)) break;
+                    if (o.alpha >= 0.f)
+                        LAUNCH(this, "g_act_bwd", 3 * ob, ob / 4,
+                               g_act_bwd(stream, (size_t)nelem(B, o.out.d), o.out.g.p, o.out.d.p, o.alpha));
+                    LAUNCH(this, "g_conv_wgrad", ob + ib, flops,
+                           g_conv_wgrad(stream, B, o.inA.d, o.inB.d, o.out.g, g + o.w_off, g + o.b_off, o.k));
+                    if (o.need_din)
+                        LAUNCH(this, "g_conv_dgrad", ob + ib, flops,
+                               g_conv_dgrad(stream, B, o.out.g, p + o.w_off, o.inA.g, o.accA, o.inB.g, o.accB, o.k));
+                    break;
+                }
+                case OP_BN: {
+                    double tb = 4.0 * nelem(B, o.inA.d);
+                    double n = (double)B * o.inA.d.H * o.inA.d.W;
+                    LAUNCH(this, "g_bn_bwd_reduce", 2 * tb, tb,
+                           g_bn_bwd_reduce(stream, B, o.inA.d, o.out.g, o.coef, g + o.w_off, g + o.b_off));
+                    LAUNCH(this, "g_bn_bwd_apply", 3 * tb, 2 * tb,
+                           g_bn_bwd_apply(stream, B, o.inA.d, o.out.g, o.inA.g, o.accA, o.coef, p + o.w_off, g + o.w_off,
+                                          g + o.b_off, n));
+                    break;
+                }
+                case OP_POOL: {
+                    double bytes = 4.0 * (2 * nelem(B, o.inA.d) + 2 * nelem(B, o.out.d));
+                    if (!generic && fast_pool_bwd(this, B, o, bytes)) break;
+                    LAUNCH(this, "g_pool_bwd", bytes, 0,
+                           g_pool_bwd(stream, B, o.inA.d, o.out.d, o.out.g, o.inA.g, o.accA, o.k));
+                    break;
+                }
+                case OP_TCONV: {
+                    double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * nelem(B, o.inA.d);
+                    double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
+                    if (!generic && fast_tconv_bwd(this, B, o, ob, ib, flops)) break;
+                    LAUNCH(this, "g_tconv_wgrad", ob + ib, flops,
+                           g_tconv_wgrad(stream, B, o.inA.d, o.out.g, g + o.w_off, g + o.b_off, o.k));
+                    LAUNCH(this, "g_tconv_dgrad", ob + ib, flops,
+                           g_tconv_dgrad(stream, B, o.out.g, p + o.w_off, o.inA.g, o.accA, o.k));
+                    break;
+                }
+            }
+        }
+        if (desc.l2 > 0.f) {
+            for (auto& pi : params) {
+                if (!pi.trainable || pi.name.size() < 7 || pi.name.rfind(".kernel") != pi.name.size() - 7) continue;
+                LAUNCH(this, "g_l2", 12.0 * pi.size, 4.0 * pi.size,
+                       g_l2(stream, (size_t)pi.size, p + pi.offset, g + pi.offset, desc.l2, scalars));
+            }
+        }
+    } else if (desc.l2 > 0.f) {
+        // evaluation: Keras adds the regulariser to the reported loss as well; it needs no gradient here.
+        // (g is scratch in this mode.)
+        for (auto& pi : params) {
+            if (!pi.trainable || pi.name.size() < 7 || pi.name.rfind(".kernel") != pi.name.size() - 7) continue;
+            LAUNCH(this, "g_l2", 12.0 * pi.size, 4.0 * pi.size,
+                   g_l2(stream, (size_t)pi.size, p + pi.offset, g + pi.offset, desc.l2, scalars));
+        }
+    }
+    LAUNCH(this, "g_finalize_scalars", 0, 0,
+           g_finalize_scalars(stream, scalars, cfg, (double)npix, 1.0 / ((double)outH * outW * B), out5));
+    return DNNCA_OK;
+}
+
+int Model::optimizer_step(float lr) {
+    float gscale = 1.0f;
+    if (world > 1 && !dry) {
+        // one all-reduce over [gradients ..., loss]: MirroredStrategy's cross-replica sum (engine.py:262) [TF-2.6]
+        ncclResult_t r = ncclAllReduce(g, g, (size_t)nT + 1, ncclFloat, ncclSum, comm, stream);
+        if (r != ncclSuccess) { set_error("ncclAllReduce: %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
+        gscale = 1.0f / (float)world;
+    }
+    iterations += dry ? 0 : 1;
+    double t = (double)(dry ? 1 : iterations);
+    float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+    LAUNCH(this, "g_adam", 28.0 * nT, 10.0 * nT, g_adam(stream, (size_t)nT, p, g, m, v, lr_t, beta1, beta2, eps, gscale));
+    return DNNCA_OK;
+}
+
+}  // namespace dnnca
+
+// =================================================================================================== C ABI
+using namespace dnnca;
+
+#define MODEL(h)                                             \
+    Model* M = reinterpret_cast<Model*>(h);                  \
+    if (!M) { set_error("null model handle"); return DNNCA_EINVAL; }
+
+extern "C" {
+
+const char* dnnca_version(void) { return "dnnca 0.1 (gfx950)"; }
+const char* dnnca_last_error(void) { return g_err; }
+
+int dnnca_device_count(int* count) {
+    if (!count) return DNNCA_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return DNNCA_EHIP; }
+    *count = n;
+    return DNNCA_OK;
+}
+
+int dnnca_init(int device_ordinal) {
+    HIP_TRY(hipSetDevice(device_ordinal));
+    return DNNCA_OK;
+}
+
+int dnnca_model_create(const dnnca_model_desc* desc, void** model_out) {
+    if (!desc || !model_out) { set_error("null argument"); return DNNCA_EINVAL; }
+    *model_out = nullptr;
+    Model* M = new Model();
+    M->desc = *desc;
+    if (M->desc.n_conv == 0) M->desc.n_conv = 2;
+    hipError_t e = hipGetDevice(&M->device);
+    if (e != hipSuccess) { set_error("no HIP device: %s", hipGetErrorString(e)); delete M; return DNNCA_EHIP; }
+    e = hipStreamCreateWithFlags(&M->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); M->stream = nullptr; delete M; return DNNCA_EHIP; }
+    int rc = M->build();
+    if (rc != DNNCA_OK) { delete M; return rc; }
+    *model_out = M;
+    return DNNCA_OK;
+}
+
+int dnnca_model_destroy(void* model) {
+    MODEL(model);
+    (void)hipStreamSynchronize(M->stream);
+    delete M;
+    return DNNCA_OK;
+}
+
+int dnnca_param_count(void* model, int* count) {
+    MODEL(model);
+    *count = (int)M->params.size();
+    return DNNCA_OK;
+}
+
+int dnnca_param_info(void* model, int index, char* name, size_t name_cap, int64_t shape[4], int* ndim, int* trainable,
+                     int64_t* offset) {
+    MODEL(model);
+    if (index < 0 || index >= (int)M->params.size()) { set_error("param index out of range"); return DNNCA_EINVAL; }
+    const ParamInfo& pi = M->params[index];
+    if (name && name_cap) snprintf(name, name_cap, "%s", pi.name.c_str());
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = pi.shape[i];
+    if (ndim) *ndim = pi.ndim;
+    if (trainable) *trainable = pi.trainable;
+    if (offset) *offset = pi.offset;
+    return DNNCA_OK;
+}
+
+int dnnca_num_trainable(void* model, int64_t* n) { MODEL(model); *n = M->nT; return DNNCA_OK; }
+int dnnca_num_state(void* model, int64_t* n) { MODEL(model); *n = M->nS; return DNNCA_OK; }
+
+static int copy_flat(Model* M, float* dev, int64_t have, const float* src, float* dst, int64_t n) {
+    if (n != have) { set_error("flat vector length %lld != %lld", (long long)n, (long long)have); return DNNCA_EINVAL; }
+    if (n == 0) return DNNCA_OK;
+    if (src) HIP_TRY(hipMemcpyAsync(dev, src, (size_t)n * 4, hipMemcpyHostToDevice, M->stream));
+    if (dst) HIP_TRY(hipMemcpyAsync(dst, dev, (size_t)n * 4, hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    return DNNCA_OK;
+}
+
+int dnnca_set_params(void* model, const float* flat, int64_t n) { MODEL(model); return copy_flat(M, M->p, M->nT, flat, nullptr, n); }
+int dnnca_get_params(void* model, float* flat, int64_t n) { MODEL(model); return copy_flat(M, M->p, M->nT, nullptr, flat, n); }
+int dnnca_set_state(void* model, const float* flat, int64_t n) { MODEL(model); return copy_flat(M, M->state, M->nS, flat, nullptr, n); }
+int dnnca_get_state(void* model, float* flat, int64_t n) { MODEL(model); return copy_flat(M, M->state, M->nS, nullptr, flat, n); }
+int dnnca_get_grads(void* model, float* flat, int64_t n) { MODEL(model); return copy_flat(M, M->g, M->nT, nullptr, flat, n); }
+
+int dnnca_set_opt_state(void* model, const float* m, const float* v, int64_t n, int64_t iterations) {
+    MODEL(model);
+    DN_TRY(copy_flat(M, M->m, M->nT, m, nullptr, n));
+    DN_TRY(copy_flat(M, M->v, M->nT, v, nullptr, n));
+    M->iterations = iterations;
+    return DNNCA_OK;
+}
+
+int dnnca_get_opt_state(void* model, float* m, float* v, int64_t n, int64_t* iterations) {
+    MODEL(model);
+    DN_TRY(copy_flat(M, M->m, M->nT, nullptr, m, n));
+    DN_TRY(copy_flat(M, M->v, M->nT, nullptr, v, n));
+    if (iterations) *iterations = M->iterations;
+    return DNNCA_OK;
+}
+
+int dnnca_set_adam(void* model, float beta1, float beta2, float epsilon) {
+    MODEL(model);
+    M->beta1 = beta1;
+    M->beta2 = beta2;
+    M->eps = epsilon;
+    return DNNCA_OK;
+}
+
+static int read_out(Model* M, dnnca_step_out* out) {
+    float h[5];
+    HIP_TRY(hipMemcpyAsync(h, M->out5, sizeof(h), hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    DN_TRY(M->flush_profile());
+    out->loss = h[0] / (float)M->world;   // after the all-reduce the slot holds the sum over ranks of the local means
+    out->positive_rate = h[1];
+    out->weight = h[2];
+    out->label_min = h[3];
+    out->label_max = h[4];
+    // utils/losses.py:91-92 assert_on_max / assert_on_min, :30 assert_on_weight
+    if (h[4] > 1.0f || h[3] < 0.0f) { set_error("label outside [0, 1]: min %g max %g (assert_on_min/assert_on_max)", h[3], h[4]); return DNNCA_EASSERT; }
+    if (h[2] < 0.0f) { set_error("negative class weight %g (assert_on_weight)", h[2]); return DNNCA_EASSERT; }
+    return DNNCA_OK;
+}
+
+int dnnca_forward_dev(void* model, const float* x_dev, int batch, int training) {
+    MODEL(model);
+    DN_TRY(M->forward(x_dev, batch, training != 0));
+    size_t npix = (size_t)batch * M->outH * M->outW;
+    LAUNCH(M, "g_sigmoid", 8.0 * npix, 4.0 * npix, g_sigmoid(M->stream, npix, M->logits, M->prob));
+    return DNNCA_OK;
+}
+
+int dnnca_forward(void* model, const float* x_nhwc, int batch, int training, float* prob_out, float* logit_out) {
+    MODEL(model);
+    if (batch < 1 || batch > M->desc.max_batch) { set_error("batch %d outside [1, %d]", batch, M->desc.max_batch); return DNNCA_EINVAL; }
+    size_t nx = (size_t)batch * M->desc.height * M->desc.width * M->desc.in_channels;
+    size_t npix = (size_t)batch * M->outH * M->outW;
+    HIP_TRY(hipMemcpyAsync(M->x_stage, x_nhwc, nx * 4, hipMemcpyHostToDevice, M->stream));
+    DN_TRY(dnnca_forward_dev(model, M->x_stage, batch, training));
+    if (prob_out) HIP_TRY(hipMemcpyAsync(prob_out, M->prob, npix * 4, hipMemcpyDeviceToHost, M->stream));
+    if (logit_out) HIP_TRY(hipMemcpyAsync(logit_out, M->logits, npix * 4, hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    return M->flush_profile();
+}
+
+int dnnca_train_step_dev(void* model, const float* x_dev, const float* y_dev, int batch, float lr, const dnnca_loss_cfg* cfg,
+                         dnnca_step_out* out) {
+    MODEL(model);
+    if (!cfg) { set_error("null loss cfg"); return DNNCA_EINVAL; }
+    DN_TRY(M->forward(x_dev, batch, true));
+    DN_TRY(M->loss_and_backward(y_dev, batch, *cfg, true));
+    DN_TRY(M->optimizer_step(lr));
+    if (out) return read_out(M, out);
+    return DNNCA_OK;
+}
+
+int dnnca_train_step(void* model, const float* x_nhwc, const float* y_hw, int batch, float lr, const dnnca_loss_cfg* cfg,
+                     dnnca_step_out* out) {
+    MODEL(model);
+    if (batch < 1 || batch > M->desc.max_batch) { set_error("batch %d outside [1, %d]", batch, M->desc.max_batch); return DNNCA_EINVAL; }
+    size_t nx = (size_t)batch * M->desc.height * M->desc.width * M->desc.in_channels;
+    size_t npix = (size_t)batch * M->outH * M->outW;
+    HIP_TRY(hipMemcpyAsync(M->x_stage, x_nhwc, nx * 4, hipMemcpyHostToDevice, M->stream));
+    HIP_TRY(hipMemcpyAsync(M->y_stage, y_hw, npix * 4, hipMemcpyHostToDevice, M->stream));
+    dnnca_step_out tmp;
+    return dnnca_train_step_dev(model, M->x_stage, M->y_stage, batch, lr, cfg, out ? out : &tmp);
+}
+
+int dnnca_eval_step(void* model, const float* x_nhwc, const float* y_hw, int batch, const dnnca_loss_cfg* cfg,
+                    dnnca_step_out* out, float* prob_out) {
+    MODEL(model);
+    if (!cfg) { set_error("null loss cfg"); return DNNCA_EINVAL; }
+    if (batch < 1 || batch > M->desc.max_batch) { set_error("batch %d outside [1, %d]", batch, M->desc.max_batch); return DNNCA_EINVAL; }
+    size_t nx = (size_t)batch * M->desc.height * M->desc.width * M->desc.in_channels;
+    size_t npix = (size_t)batch * M->outH * M->outW;
+    HIP_TRY(hipMemcpyAsync(M->x_stage, x_nhwc, nx * 4, hipMemcpyHostToDevice, M->stream));
+    HIP_TRY(hipMemcpyAsync(M->y_stage, y_hw, npix * 4, hipMemcpyHostToDevice, M->stream));
+    DN_TRY(M->forward(M->x_stage, batch, false));
+    DN_TRY(M->loss_and_backward(M->y_stage, batch, *cfg, false));
+    if (prob_out) HIP_TRY(hipMemcpyAsync(prob_out, M->prob, npix * 4, hipMemcpyDeviceToHost, M->stream));
+    dnnca_step_out tmp;
+    int world = M->world;
+    M->world = 1;   // evaluation is rank-local: the loss slot was not all-reduced
+    int rc = read_out(M, out ? out : &tmp);
+    M->world = world;
+    return rc;
+}
+
+int dnnca_last_step_out(void* model, dnnca_step_out* out) {
+    MODEL(model);
+    if (!out) return DNNCA_EINVAL;
+    return read_out(M, out);
+}
+
+int dnnca_sync(void* model) {
+    MODEL(model);
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    return M->flush_profile();
+}
+
+int dnnca_dev_alloc(void** dev_ptr, size_t bytes) {
+    if (!dev_ptr) return DNNCA_EINVAL;
+    HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 4));
+    return DNNCA_OK;
+}
+int dnnca_dev_free(void* dev_ptr) { HIP_TRY(hipFree(dev_ptr)); return DNNCA_OK; }
+int dnnca_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) { HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice)); return DNNCA_OK; }
+int dnnca_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) { HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost)); return DNNCA_OK; }
+
+int dnnca_pixel_confusion(void* model, const float* y_hw, int batch, const float* thresholds, int n, dnnca_confusion* out) {
+    MODEL(model);
+    if (n < 1 || n > 256 || !out || !thresholds || !y_hw) { set_error("bad confusion arguments"); return DNNCA_EINVAL; }
+    if (batch < 1 || batch > M->desc.max_batch) { set_error("batch out of range"); return DNNCA_EINVAL; }
+    size_t npix = (size_t)batch * M->outH * M->outW;
+    HIP_TRY(hipMemcpyAsync(M->y_stage, y_hw, npix * 4, hipMemcpyHostToDevice, M->stream));
+    HIP_TRY(hipMemcpyAsync(M->thr_dev, thresholds, (size_t)n * 4, hipMemcpyHostToDevice, M->stream));
+    HIP_TRY(hipMemsetAsync(M->conf_dev, 0, (size_t)n * 4 * 8, M->stream));
+    g_confusion(M->stream, npix, M->prob, M->y_stage, M->thr_dev, n, M->conf_dev);
+    std::vector<double> h((size_t)n * 4);
+    HIP_TRY(hipMemcpyAsync(h.data(), M->conf_dev, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    for (int i = 0; i < n; ++i) {
+        out[i].tp = h[4 * i];
+        out[i].fp = h[4 * i + 1];
+        out[i].fn = h[4 * i + 2];
+        out[i].tn = h[4 * i + 3];
+    }
+    return DNNCA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- data parallel
+int dnnca_comm_unique_id(void* id_out) {
+    if (!id_out) return DNNCA_EINVAL;
+    static_assert(sizeof(ncclUniqueId) <= DNNCA_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) { set_error("ncclGetUniqueId: %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
+    memset(id_out, 0, DNNCA_UNIQUE_ID_BYTES);
+    memcpy(id_out, &id, sizeof(id));
+    return DNNCA_OK;
+}
+
+int dnnca_comm_init(void* model, int rank, int world, const void* unique_id, size_t id_len) {
+    MODEL(model);
+    if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world %d/%d", rank, world); return DNNCA_EINVAL; }
+    M->rank = rank;
+    M->world = world;
+    if (world == 1) return DNNCA_OK;
+    if (!unique_id || id_len < sizeof(ncclUniqueId)) { set_error("unique id too short"); return DNNCA_EINVAL; }
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&M->comm, world, id, rank);
+    if (r != ncclSuccess) { set_error("ncclCommInitRank: %s", ncclGetErrorString(r)); M->comm = nullptr; M->world = 1; return DNNCA_ECOMM; }
+    return DNNCA_OK;
+}
+
+int dnnca_comm_world(void* model, int* rank, int* world) {
+    MODEL(model);
+    if (rank) *rank = M->rank;
+    if (world) *world = M->world;
+    return DNNCA_OK;
+}
+
+int dnnca_comm_average_state(void* model) {
+    MODEL(model);
+    if (M->world == 1 || M->nS == 0) return DNNCA_OK;
+    ncclResult_t r = ncclAllReduce(M->state, M->state, (size_t)M->nS, ncclFloat, ncclSum, M->comm, M->stream);
+    if (r != ncclSuccess) { set_error("ncclAllReduce(state): %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
+    g_scale(M->stream, (size_t)M->nS, M->state, 1.0f / (float)M->world);
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    return DNNCA_OK;
+}
+
+int dnnca_comm_allreduce_host(void* model, float* values, int n, int op) {
+    MODEL(model);
+    if (n < 1 || n > 256 || !values) return DNNCA_EINVAL;
+    if (M->world == 1) return DNNCA_OK;
+    float* tmp = reinterpret_cast<float*>(M->conf_dev);
+    HIP_TRY(hipMemcpyAsync(tmp, values, (size_t)n * 4, hipMemcpyHostToDevice, M->stream));
+    ncclResult_t r = ncclAllReduce(tmp, tmp, (size_t)n, ncclFloat, op == 1 ? ncclMax : ncclSum, M->comm, M->stream);
+    if (r != ncclSuccess) { set_error("ncclAllReduce(host): %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
+    HIP_TRY(hipMemcpyAsync(values, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    return DNNCA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- measurement
+int dnnca_timer_start(void* model) {
+    MODEL(model);
+    HIP_TRY(hipEventRecord(M->ev0, M->stream));
+    return DNNCA_OK;
+}
+
+int dnnca_timer_stop(void* model, float* elapsed_ms) {
+    MODEL(model);
+    HIP_TRY(hipEventRecord(M->ev1, M->stream));
+    HIP_TRY(hipEventSynchronize(M->ev1));
+    if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, M->ev0, M->ev1));
+    return M->flush_profile();
+}
+
+int dnnca_profile_enable(void* model, int mode) {
+    MODEL(model);
+    DN_TRY(M->flush_profile());
+    M->prof_mode = mode;
+    return DNNCA_OK;
+}
+
+int dnnca_profile_focus(void* model, const char* kernel_name) {
+    MODEL(model);
+    M->focus = kernel_name ? kernel_name : "";
+    return DNNCA_OK;
+}
+
+int dnnca_profile_reset(void* model) {
+    MODEL(model);
+    DN_TRY(M->flush_profile());
+    M->kstats.clear();
+    M->kid.clear();
+    return DNNCA_OK;
+}
+
+int dnnca_profile_count(void* model, int* count) {
+    MODEL(model);
+    DN_TRY(M->flush_profile());
+    *count = (int)M->kstats.size();
+    return DNNCA_OK;
+}
+
+int dnnca_profile_get(void* model, int index, char* name, size_t name_cap, int64_t* launches, double* total_ms,
+                      double* algorithmic_bytes, double* flops) {
+    MODEL(model);
+    if (index < 0 || index >= (int)M->kstats.size()) { set_error("profile index out of range"); return DNNCA_EINVAL; }
+    const KStat& k = M->kstats[index];
+    if (name && name_cap) snprintf(name, name_cap, "%s", k.name.c_str());
+    if (launches) *launches = k.launches;
+    if (total_ms) *total_ms = k.total_ms;
+    double L = k.launches ? (double)k.launches : 1.0;
+    if (algorithmic_bytes) *algorithmic_bytes = k.bytes / L;
+    if (flops) *flops = k.flops / L;
+    return DNNCA_OK;
+}
+
+int dnnca_plan_dump(void* model, char* buf, size_t cap) {
+    MODEL(model);
+    if (!buf || !cap) return DNNCA_EINVAL;
+    M->plan_text.clear();
+    M->dry = true;
+    dnnca_loss_cfg cfg = {0, 0.f, 0.f, 1.f};
+    int B = M->desc.max_batch;
+    int rc = M->forward(M->x_stage, B, true);
+    if (rc == DNNCA_OK) rc = M->loss_and_backward(M->y_stage, B, cfg, true);
+    if (rc == DNNCA_OK) rc = M->optimizer_step(1e-3f);
+    M->dry = false;
+    snprintf(buf, cap, "%s", M->plan_text.c_str());
+    return rc;
+}
+
+}  // extern "C"

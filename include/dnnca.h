@@ -1,0 +1,158 @@
+/*
+ * dnnca.h -- C ABI of libdnnca.so: the MI355X-native (gfx950, hand-written HIP) U-Net train/evaluate engine that
+ * stands in for the TensorFlow/Keras numeric back-end of yoshihikoueno/DNNCancerAnnotator's hot path.
+ *
+ * The reference has no FFI boundary of its own on this path (it is Python on top of TensorFlow); each entry point below
+ * cites the reference interface (file:line under annotator/) whose work it takes over.  The Python host
+ * (dnncancerannotator_amd/engine.py, a mirror of annotator/engine.py:36-288) binds these with ctypes; INTEGRATION.md
+ * shows the stub.
+ *
+ * Conventions: every function returns 0 on success or a negative DNNCA_E* code (message via dnnca_last_error());
+ * nothing throws across the ABI; the caller owns host buffers; the library owns device memory; tensors are NHWC float32;
+ * a model handle is bound to one HIP device + one stream and is not thread-safe; data parallel = one process per GPU,
+ * each with its own handle, joined by dnnca_comm_init (RCCL over xGMI).
+ */
+#ifndef DNNCA_H
+#define DNNCA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNNCA_OK 0
+#define DNNCA_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define DNNCA_EHIP (-2)        /* HIP runtime error (no device, launch failure, out of memory) */
+#define DNNCA_ECOMM (-3)       /* RCCL error */
+#define DNNCA_ESTATE (-4)      /* call sequence error (e.g. step before init) */
+#define DNNCA_EASSERT (-5)     /* a reference-side tf.debugging.assert_* would have fired (utils/losses.py:30,91-99) */
+
+enum { DNNCA_ARCH_UNET = 0, DNNCA_ARCH_MULMO = 1 };     /* models/tf_models/unet.py:194 UNetAnnotator, :285 MulmoUNetAnnotator */
+enum { DNNCA_PAD_VALID = 0, DNNCA_PAD_SAME = 1 };       /* model_options.padding (configs/unet.yaml:9) */
+enum { DNNCA_F32 = 0, DNNCA_BF16 = 1 };                 /* arithmetic type of the conv contractions */
+enum { DNNCA_UNIQUE_ID_BYTES = 128 };
+
+/* model_options of configs/{unet,unet_big,mulmo_unet}.yaml (unet.py:195-207) + the input element spec
+ * (engine.py:93 model.build(dataset.element_spec[0].shape)). */
+typedef struct dnnca_model_desc {
+    int32_t arch;             /* DNNCA_ARCH_* */
+    int32_t in_channels;      /* C of x[B,H,W,C]; mulmo builds one encoder per channel (unet.py:151-165) */
+    int32_t height, width;    /* must be divisible by rate^n_downsample */
+    int32_t max_batch;        /* activations are allocated once for this batch size */
+    int32_t n_filters_first;  /* unet.yaml:3 */
+    int32_t n_downsample;     /* unet.yaml:4 */
+    int32_t rate;             /* unet.yaml:5 (pool window/stride, transposed-conv kernel/stride) */
+    int32_t kernel_size;      /* unet.yaml:6 */
+    int32_t conv_stride;      /* unet.yaml:7 (only 1 is supported; the reference configs use 1) */
+    int32_t bn;               /* unet.yaml:8 */
+    int32_t padding;          /* DNNCA_PAD_* (only SAME is supported; every reference config uses same) */
+    int32_t reference_index;  /* unet.py:114 (mulmo: which encoder's skips feed the decoder) */
+    int32_t n_conv;           /* components.py:25 (2) */
+    float leaky_alpha;        /* 0 = relu; 0.3 = configs/additionals/leakyReLU.yaml */
+    float l2;                 /* 0 = none; 0.01 = configs/additionals/kernel_regularizer.yaml */
+    int32_t dtype;            /* DNNCA_F32 | DNNCA_BF16 */
+    int32_t flags;            /* bit 0: force the generic (untuned) kernels everywhere -- used by the parity tests */
+} dnnca_model_desc;
+
+/* deploy_options.loss.config of configs/additionals/deploy_options.yaml:4-7 (utils/losses.py:41-56) */
+typedef struct dnnca_loss_cfg {
+    int32_t has_weight;       /* 0: weight = 1/positive_rate (or 1 when there are no positives), losses.py:24-27 */
+    float weight;
+    float weight_add;         /* losses.py:29 */
+    float weight_mul;
+} dnnca_loss_cfg;
+
+typedef struct dnnca_step_out {
+    float loss;               /* scalar Keras loss of the step (mean over batch [+ L2]); mean over ranks under DP */
+    float positive_rate;      /* utils/losses.py:87-102 (rank-local) */
+    float weight;             /* the positive-class weight actually applied (rank-local) */
+    float label_min, label_max;
+} dnnca_step_out;
+
+/* pixel confusion counts at one threshold (prob > threshold: Keras Precision/Recall convention, metrics.yaml:2-6) */
+typedef struct dnnca_confusion {
+    double tp, fp, fn, tn;
+} dnnca_confusion;
+
+/* ---- process / device ---------------------------------------------------------------------------------------- */
+const char* dnnca_version(void);
+const char* dnnca_last_error(void);
+int dnnca_device_count(int* count);
+int dnnca_init(int device_ordinal);                 /* hipSetDevice; engine.py:260-263 (strategy creation) */
+
+/* ---- model life-cycle: engine.py:254-288 from_config + engine.py:93 model.build ------------------------------- */
+int dnnca_model_create(const dnnca_model_desc* desc, void** model_out);
+int dnnca_model_destroy(void* model);
+
+/* variables in Keras creation order (components.py:69-75,226-233,292-312; unet.py:166-176,273-277).
+ * Conv2D kernels are HWIO, Conv2DTranspose kernels [kh,kw,Cout,Cin]. offset = position in the trainable (or state) flat vector. */
+int dnnca_param_count(void* model, int* count);
+int dnnca_param_info(void* model, int index, char* name, size_t name_cap, int64_t shape[4], int* ndim,
+                     int* trainable, int64_t* offset);
+int dnnca_num_trainable(void* model, int64_t* n);   /* floats in the trainable flat vector */
+int dnnca_num_state(void* model, int64_t* n);       /* floats in the non-trainable flat vector (BN moving statistics) */
+
+/* model.load_weights / save_weights (engine.py:197,224-231, ModelCheckpoint engine.py:103-106) */
+int dnnca_set_params(void* model, const float* flat, int64_t n);
+int dnnca_get_params(void* model, float* flat, int64_t n);
+int dnnca_set_state(void* model, const float* flat, int64_t n);
+int dnnca_get_state(void* model, float* flat, int64_t n);
+int dnnca_get_grads(void* model, float* flat, int64_t n);          /* gradients of the last train step (parity tests) */
+/* Adam slots + iteration counter (engine.py:276-284); checkpoint / auto-resume (engine.py:67-78) */
+int dnnca_set_opt_state(void* model, const float* m, const float* v, int64_t n, int64_t iterations);
+int dnnca_get_opt_state(void* model, float* m, float* v, int64_t n, int64_t* iterations);
+int dnnca_set_adam(void* model, float beta1, float beta2, float epsilon);
+
+/* ---- the hot path, host buffers ------------------------------------------------------------------------------ */
+/* UNetAnnotator.call (unet.py:279-282): probabilities [B,H,W,1]; logits = the tensor Keras caches as _keras_logits */
+int dnnca_forward(void* model, const float* x_nhwc, int batch, int training, float* prob_out, float* logit_out);
+/* keras Model.train_step under engine.py:126-135: forward(training=True) + TFWeightedCrossentropy (losses.py:60-72)
+ * + backward + [RCCL all-reduce] + Adam apply with learning rate lr (LearningRateScheduler, engine.py:97-100) */
+int dnnca_train_step(void* model, const float* x_nhwc, const float* y_hw, int batch, float lr,
+                     const dnnca_loss_cfg* cfg, dnnca_step_out* out);
+/* keras Model.test_step under engine.py:198-203: forward(training=False) + loss; optional probabilities */
+int dnnca_eval_step(void* model, const float* x_nhwc, const float* y_hw, int batch,
+                    const dnnca_loss_cfg* cfg, dnnca_step_out* out, float* prob_out);
+
+/* ---- the hot path, device-resident batches (what bench.py times) ---------------------------------------------- */
+int dnnca_dev_alloc(void** dev_ptr, size_t bytes);
+int dnnca_dev_free(void* dev_ptr);
+int dnnca_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
+int dnnca_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
+/* same as dnnca_train_step with x/y already in HBM; asynchronous on the model's stream; out may be NULL (no sync) */
+int dnnca_train_step_dev(void* model, const float* x_dev, const float* y_dev, int batch, float lr,
+                         const dnnca_loss_cfg* cfg, dnnca_step_out* out);
+int dnnca_forward_dev(void* model, const float* x_dev, int batch, int training);   /* results stay on the device */
+int dnnca_last_step_out(void* model, dnnca_step_out* out);        /* synchronises, then reads the last step's scalars */
+int dnnca_sync(void* model);
+
+/* pixel TP/FP/FN/TN of the last forward/eval probabilities against y at n thresholds (metrics.yaml:2-23 pixel metrics;
+ * utils/metrics.py:37-77 FBetaScore builds on them). y_hw is a host buffer [B,H,W]. */
+int dnnca_pixel_confusion(void* model, const float* y_hw, int batch, const float* thresholds, int n, dnnca_confusion* out);
+
+/* ---- data parallel: tf.distribute.MirroredStrategy (engine.py:260-263) re-done as one process per GPU + RCCL ---- */
+int dnnca_comm_unique_id(void* id_out /* DNNCA_UNIQUE_ID_BYTES */);
+int dnnca_comm_init(void* model, int rank, int world, const void* unique_id, size_t id_len);   /* world == 1: no-op */
+int dnnca_comm_world(void* model, int* rank, int* world);
+int dnnca_comm_average_state(void* model);          /* BN moving statistics: mean over ranks before a checkpoint */
+int dnnca_comm_allreduce_host(void* model, float* values, int n, int op /* 0 sum, 1 max */);
+
+/* ---- measurement: HIP events on the model's stream ------------------------------------------------------------- */
+int dnnca_timer_start(void* model);
+int dnnca_timer_stop(void* model, float* elapsed_ms);  /* synchronises */
+/* per-kernel accounting: when enabled every launch is bracketed by HIP events on the model's stream */
+int dnnca_profile_enable(void* model, int mode /* 0 off, 1 all kernels, 2 only the kernel named by dnnca_profile_focus */);
+int dnnca_profile_focus(void* model, const char* kernel_name);
+int dnnca_profile_reset(void* model);
+int dnnca_profile_count(void* model, int* count);
+int dnnca_profile_get(void* model, int index, char* name, size_t name_cap, int64_t* launches, double* total_ms,
+                      double* algorithmic_bytes, double* flops);   /* bytes/flops are per launch (mean) */
+/* the launch schedule of one train step: name + algorithmic bytes/flops per launch (for DESIGN.md and bench.py) */
+int dnnca_plan_dump(void* model, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNNCA_H */
