@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- MRI slices/s of one train step (forward + weighted-BCE + backward + Adam) of configs/unet.yaml on
+synthetic 512x512x1 batches, 8 slices per GPU, fp32, on N MI355X (weak scaling: global batch = 8 N).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; gradients are summed by ONE RCCL all-reduce per step inside libdnnca (no torch in the workers:
+torch bundles its own ROCm runtime, which must not share a process with libdnnca).  The RCCL unique id travels through
+a file keyed by the launcher's pid.  Rank 0 prints one JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dnncancerannotator_amd import device as dev                      # noqa: E402
+from dnncancerannotator_amd.synthetic import synthetic_batch         # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec; 6.29 TB/s measured float4 copy)
+H = W = 512
+C = 1
+BATCH_PER_GPU = 8              # configs[1]: configs/unet.yaml, batch 8 512x512x1, fp32, 1 x MI355X
+UNET_YAML = dict(n_filters_first=3, n_downsample=3, rate=2, kernel_size=3, conv_stride=1, bn=False, padding='same')
+
+
+def rendezvous(rank, world):
+    """RCCL unique id: rank 0 creates it and publishes it in a file named after the launcher (parent) pid."""
+    if world == 1:
+        return None
+    key = '%s_%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
+    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'dnnca_rdzv_%s.id' % key)
+    if rank == 0:
+        uid = dev.DeviceModel.comm_unique_id()
+        tmp = path + '.tmp%d' % os.getpid()
+        with open(tmp, 'wb') as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            if os.path.getmtime(path) > t0 - 600:
+                with open(path, 'rb') as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    return uid
+        except OSError:
+            pass
+        if time.time() - t0 > 300:
+            raise RuntimeError('timed out waiting for the RCCL unique id at %s' % path)
+        time.sleep(0.05)
+
+
+def cpu_baseline(sample_steps=3):
+    """The numpy oracle (a port: TensorFlow, the reference's CPU back-end, is not installed anywhere) timed on this
+    host on a bounded sample of the same workload: `sample_steps` train steps of one 8-slice batch."""
+    from oracle import unet_oracle as O
+    spec = O.ModelSpec('unet', C, **UNET_YAML)
+    params = O.init_params(spec, seed=2)
+    x, y = synthetic_batch(BATCH_PER_GPU, H, W, C)
+    m, v = {}, {}
+    O.train_step(spec, params, m, v, 1, x[:1], y[:1], 1e-3, dict(weight_mul=3.0))      # page in / warm BLAS
+    t0 = time.time()
+    for t in range(sample_steps):
+        _, params, _, _ = O.train_step(spec, params, m, v, t + 1, x, y, 1e-3, dict(weight_mul=3.0))
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = 1
+    return {'value': round(sample_steps * BATCH_PER_GPU / dt, 3), 'unit': 'slices/s', 'cores': int(threads), 'kind': 'port',
+            'sample': '%d train steps of one %dx%dx%dx%d batch (numpy oracle, fp32; host has %d cores)' % (
+                sample_steps, BATCH_PER_GPU, H, W, C, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--generic', action='store_true', help='force the untuned generic kernels')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    dev.init_device(local_rank)
+    model = dev.DeviceModel('unet', C, H, W, BATCH_PER_GPU, force_generic=args.generic, **UNET_YAML)
+    model.init_glorot(seed=2)          # same weights on every rank (random-init weights of the named architecture)
+    uid = rendezvous(rank, world)
+    model.comm_init(rank, world, uid)
+
+    # rank-local shard of the global batch, resident in HBM before the timed region
+    x, y = synthetic_batch(BATCH_PER_GPU, H, W, C, seed_x=100 + rank, seed_y=200 + rank)
+    xb, yb = dev.DeviceBuffer(x), dev.DeviceBuffer(y)
+    cfg = model.loss_cfg(weight_mul=3.0)            # configs/additionals/deploy_options.yaml:5-7
+    lr = 1e-3
+
+    def barrier():
+        model.sync()
+        if world > 1:
+            model.comm_allreduce([0.0])
+        model.sync()
+
+    for _ in range(args.warmup):
+        model.train_step_dev(xb, yb, BATCH_PER_GPU, lr, cfg)
+    model.sync()
+
+    # which kernel dominates?  two fully instrumented steps outside the timed region
+    model.profile_reset()
+    model.profile_enable(1)
+    for _ in range(2):
+        model.train_step_dev(xb, yb, BATCH_PER_GPU, lr, cfg)
+    model.sync()
+    table = sorted(model.profile(), key=lambda r: -r[2])
+    dominant = table[0][0]
+    model.profile_enable(0)
+    model.profile_reset()
+    model.profile_enable(2, focus=dominant)   # HIP events around the dominant kernel only, on the launch stream
+
+    barrier()
+    t0 = time.perf_counter()
+    model.timer_start()
+    for _ in range(args.steps):
+        model.train_step_dev(xb, yb, BATCH_PER_GPU, lr, cfg)
+    ev_ms = model.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    elapsed = float(model.comm_allreduce([wall], op='max')[0]) if world > 1 else wall
+    out = model.last_step_out()
+    prof = {r[0]: r for r in model.profile()}
+    model.profile_enable(0)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * BATCH_PER_GPU * args.steps / elapsed
+        name, launches, total_ms, bytes_per, flops_per = prof[dominant]
+        avg_ms = total_ms / max(launches, 1)
+        achieved = bytes_per / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dominant)
+        line = {
+            'metric': 'MRI slices/sec (fwd+bwd) unet 512x512 bs=8', 'value': round(value, 2), 'unit': 'slices/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs/unet.yaml train step (fwd + weighted BCE + bwd + Adam), batch %d x 512x512x1 '
+                                   'per GPU, fp32, random-init weights' % BATCH_PER_GPU,
+                       'global_batch': world * BATCH_PER_GPU, 'parallelism': 'dp%d' % world,
+                       'kernels': 'generic' if args.generic else 'tuned'},
+            'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'launches': int(launches), 'avg_launch_us': round(avg_ms * 1e3, 2),
+                         'algorithmic_bytes_per_launch': bytes_per,
+                         'share_of_step': round(total_ms / (ev_ms if ev_ms > 0 else 1e9), 4)},
+            'hip_event_ms_per_step': round(ev_ms / args.steps, 4),
+            'final_loss': round(float(out.loss), 6),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1 and rank == 0:
+        try:
+            key = '%s_%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
+            os.remove(os.path.join(os.environ.get('TMPDIR', '/tmp'), 'dnnca_rdzv_%s.id' % key))
+        except OSError:
+            pass
+    model.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -5,11 +5,21 @@
 
 namespace dnnca {
 
+int fast_prepare(Model* m);     // per-step operand preparation (weights -> MFMA B operands)
+int fast_finish_backward(Model* m);   // folds the weight-gradient slabs into the flat gradient vector
+void fast_release(Model* m);    // drop the per-model plan
 bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 bool fast_pool_fwd(Model* m, int B, Op& o, double bytes);
 bool fast_pool_bwd(Model* m, int B, Op& o, double bytes);
 bool fast_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops);
 bool fast_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
+bool fast_tconv_dgrad(Model* m, int B, Op& o, double bytes, double flops);
+bool fast_pool_supported(const Model* m, const Op& o);
+bool fast_tconv_supported(const Model* m, const Op& o);
+bool fast_head_supported(const Model* m, const Op& o);
+bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cfg& cfg, float gscale, double bytes);
+bool fast_label_stats(Model* m, size_t n, const float* y);
+void fast_plan_masks(Model* m);   // decides maskA/maskB/premasked for every op (static per model)
 
 }  // namespace dnnca

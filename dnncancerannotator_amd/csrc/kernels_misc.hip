@@ -1,0 +1,454 @@
+// kernels_misc.hip -- tuned HBM-bound kernels around the convolutions of configs/unet.yaml: 2x2 max-pool (fwd/bwd),
+// 2x2 stride-2 transposed conv (fwd / data gradient), and the fused head: 1x1 conv -> logits -> weighted BCE ->
+// dlogits -> head gradients -> gradient of the last feature map, all from ONE read of the feature map.
+// Every thread moves 16-byte vectors; 12 floats (= 4/2/1 pixels of 3/6/12 channels) are the common work unit so that
+// the non-power-of-two pixel sizes stay 16-byte aligned.
+#include "fast.h"
+#include "kernels.h"
+
+namespace dnnca {
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL void ld4(float* d, const float* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+}
+DEVINL void st4(float* p, const float* s) { *reinterpret_cast<float4*>(p) = make_float4(s[0], s[1], s[2], s[3]); }
+
+static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
+
+// ------------------------------------------------------------------------------------------------ max pool 2x2 / 2
+// one thread = 12 output floats = 24 input floats of each of the two input rows
+template <int C>
+__global__ __launch_bounds__(256) void k_pool2_fwd(const float* __restrict__ in, float* __restrict__ out, int B, int Ho,
+                                                   int Wo) {
+    const int cpr = Wo * C / 12;                       // chunks per output row
+    const int total = B * Ho * cpr;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int ch = id % cpr, row = id / cpr;           // row = b*Ho + oy
+    const float* r0 = in + ((size_t)row * 2) * (2 * Wo * C) + ch * 24;
+    const float* r1 = r0 + 2 * Wo * C;
+    float a[24], b[24], o[12];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        ld4(a + 4 * v, r0 + 4 * v);
+        ld4(b + 4 * v, r1 + 4 * v);
+    }
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+        const int i0 = (2 * (f / C)) * C + f % C, i1 = i0 + C;
+        o[f] = fmaxf(fmaxf(a[i0], a[i1]), fmaxf(b[i0], b[i1]));
+    }
+    float* op = out + (size_t)row * (Wo * C) + ch * 12;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) st4(op + 4 * v, o + 4 * v);
+}
+
+// din = ((acc ? din : 0) + route(dout)) * (mask ? act'(in) : 1); the first maximum in row-major window order gets it
+template <int C>
+__global__ __launch_bounds__(256) void k_pool2_bwd(const float* __restrict__ in, const float* __restrict__ dout,
+                                                   float* __restrict__ din, int B, int Ho, int Wo, int acc, int mask,
+                                                   float alpha) {
+    const int cpr = Wo * C / 12;
+    const int total = B * Ho * cpr;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int ch = id % cpr, row = id / cpr;
+    const size_t o0 = ((size_t)row * 2) * (2 * Wo * C) + ch * 24, o1 = o0 + 2 * Wo * C;
+    float a[24], b[24], g[12], da[24], db[24];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        ld4(a + 4 * v, in + o0 + 4 * v);
+        ld4(b + 4 * v, in + o1 + 4 * v);
+    }
+    const float* gp = dout + (size_t)row * (Wo * C) + ch * 12;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) ld4(g + 4 * v, gp + 4 * v);
+    if (acc) {
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            ld4(da + 4 * v, din + o0 + 4 * v);
+            ld4(db + 4 * v, din + o1 + 4 * v);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) da[i] = db[i] = 0.f;
+    }
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+        const int i0 = (2 * (f / C)) * C + f % C, i1 = i0 + C;
+        const float m = fmaxf(fmaxf(a[i0], a[i1]), fmaxf(b[i0], b[i1]));
+        const bool h0 = a[i0] == m, h1 = !h0 && a[i1] == m, h2 = !h0 && !h1 && b[i0] == m, h3 = !h0 && !h1 && !h2;
+        da[i0] += h0 ? g[f] : 0.f;
+        da[i1] += h1 ? g[f] : 0.f;
+        db[i0] += h2 ? g[f] : 0.f;
+        db[i1] += h3 ? g[f] : 0.f;
+    }
+    if (mask) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            da[i] *= a[i] > 0.f ? 1.0f : alpha;
+            db[i] *= b[i] > 0.f ? 1.0f : alpha;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        st4(din + o0 + 4 * v, da + 4 * v);
+        st4(din + o1 + 4 * v, db + 4 * v);
+    }
+}
+
+bool fast_pool_supported(const Model* m, const Op& o) {
+    if (o.type != OP_POOL || o.k != 2 || m->desc.dtype != DNNCA_F32) return false;
+    if (!dense(o.inA.d) || !dense(o.out.d)) return false;
+    const int C = o.out.d.C;
+    if (!(C == 3 || C == 6 || C == 12)) return false;
+    return (o.out.d.W * C) % 12 == 0;
+}
+
+bool fast_pool_fwd(Model* m, int B, Op& o, double bytes) {
+    if (!fast_pool_supported(m, o)) return false;
+    const int C = o.out.d.C, Ho = o.out.d.H, Wo = o.out.d.W;
+    const int total = B * Ho * (Wo * C / 12);
+    dim3 grid((total + 255) / 256);
+#define POOL_CASE(c)                                                                                      \
+    if (C == c) {                                                                                         \
+        LAUNCH(m, "pool2_fwd_" #c, bytes, 0,                                                              \
+               hipLaunchKernelGGL(k_pool2_fwd<c>, grid, dim3(256), 0, m->stream, o.inA.d.p, o.out.d.p, B, Ho, Wo)); \
+        return true;                                                                                      \
+    }
+    POOL_CASE(3) POOL_CASE(6) POOL_CASE(12)
+#undef POOL_CASE
+    return false;
+}
+
+bool fast_pool_bwd(Model* m, int B, Op& o, double bytes) {
+    if (!fast_pool_supported(m, o)) return false;
+    const int C = o.out.d.C, Ho = o.out.d.H, Wo = o.out.d.W;
+    const int total = B * Ho * (Wo * C / 12);
+    dim3 grid((total + 255) / 256);
+#define POOL_CASE(c)                                                                                      \
+    if (C == c) {                                                                                         \
+        LAUNCH(m, "pool2_bwd_" #c, bytes, 0,                                                              \
+               hipLaunchKernelGGL(k_pool2_bwd<c>, grid, dim3(256), 0, m->stream, o.inA.d.p, o.out.g.p, o.inA.g.p, B, Ho, \
+                                  Wo, (int)o.accA, (int)o.maskA, o.mask_alpha));                          \
+        return true;                                                                                      \
+    }
+    POOL_CASE(3) POOL_CASE(6) POOL_CASE(12)
+#undef POOL_CASE
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ transposed conv 2x2/2
+// forward: one thread = one input pixel and one output row a (uniform per block row) -> 2 output pixels
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_tconv2_fwd(const float* __restrict__ in, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int B, int H,
+                                                    int W) {
+    const int a = blockIdx.y;
+    const int total = B * H * W;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int j = id % W, bi = id / W;        // bi = b*H + i
+    float x[CIN];
+    const float* ip = in + (size_t)id * CIN;
+    if constexpr (CIN % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < CIN / 4; ++v) ld4(x + 4 * v, ip + 4 * v);
+    } else {
+#pragma unroll
+        for (int v = 0; v < CIN / 2; ++v) {
+            float2 t = *reinterpret_cast<const float2*>(ip + 2 * v);
+            x[2 * v] = t.x;
+            x[2 * v + 1] = t.y;
+        }
+    }
+    float o[2 * COUT];
+    const float* wa = w + a * 2 * COUT * CIN;     // [e][co][ci]
+#pragma unroll
+    for (int r = 0; r < 2 * COUT; ++r) {
+        float s = bias[r % COUT];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) s = fmaf(x[ci], wa[r * CIN + ci], s);
+        o[r] = s;
+    }
+    float* op = out + (((size_t)bi * 2 + a) * (2 * W) + 2 * j) * COUT;
+    if constexpr ((2 * COUT) % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < 2 * COUT / 4; ++v) st4(op + 4 * v, o + 4 * v);
+    } else {
+#pragma unroll
+        for (int v = 0; v < COUT; ++v) *reinterpret_cast<float2*>(op + 2 * v) = make_float2(o[2 * v], o[2 * v + 1]);
+    }
+}
+
+// data gradient: one thread = one input pixel; din = ((acc ? din : 0) + sum dout * W) * (mask ? act'(in) : 1)
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_tconv2_dgrad(const float* __restrict__ dout, const float* __restrict__ w,
+                                                      const float* __restrict__ in, float* __restrict__ din, int B, int H,
+                                                      int W, int acc, int mask, float alpha) {
+    const int total = B * H * W;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int j = id % W, bi = id / W;
+    float d[CIN];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) d[ci] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        float g[2 * COUT];
+        const float* gp = dout + (((size_t)bi * 2 + a) * (2 * W) + 2 * j) * COUT;
+        if constexpr ((2 * COUT) % 4 == 0) {
+#pragma unroll
+            for (int v = 0; v < 2 * COUT / 4; ++v) ld4(g + 4 * v, gp + 4 * v);
+        } else {
+#pragma unroll
+            for (int v = 0; v < COUT; ++v) {
+                float2 t = *reinterpret_cast<const float2*>(gp + 2 * v);
+                g[2 * v] = t.x;
+                g[2 * v + 1] = t.y;
+            }
+        }
+        const float* wa = w + a * 2 * COUT * CIN;
+#pragma unroll
+        for (int r = 0; r < 2 * COUT; ++r)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) d[ci] = fmaf(g[r], wa[r * CIN + ci], d[ci]);
+    }
+    float* dp = din + (size_t)id * CIN;
+    if (acc) {
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) d[ci] += dp[ci];
+    }
+    if (mask) {
+        const float* ip = in + (size_t)id * CIN;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) d[ci] *= ip[ci] > 0.f ? 1.0f : alpha;
+    }
+    if constexpr (CIN % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < CIN / 4; ++v) st4(dp + 4 * v, d + 4 * v);
+    } else {
+#pragma unroll
+        for (int v = 0; v < CIN / 2; ++v) *reinterpret_cast<float2*>(dp + 2 * v) = make_float2(d[2 * v], d[2 * v + 1]);
+    }
+}
+
+bool fast_tconv_supported(const Model* m, const Op& o) {
+    if (o.type != OP_TCONV || o.k != 2 || m->desc.dtype != DNNCA_F32) return false;
+    if (!dense(o.inA.d) || !dense(o.out.d)) return false;
+    const int CI = o.inA.d.C, CO = o.out.d.C;
+    if (!((CI == 12 && CO == 12) || (CI == 12 && CO == 6) || (CI == 6 && CO == 3))) return false;
+    return o.inA.d.W % 4 == 0;
+}
+
+#define TCONV_CASES(X) X(12, 12) X(12, 6) X(6, 3)
+
+bool fast_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
+    if (!fast_tconv_supported(m, o)) return false;
+    const int CI = o.inA.d.C, CO = o.out.d.C, H = o.inA.d.H, W = o.inA.d.W;
+    dim3 grid((B * H * W + 255) / 256, 2);
+#define X(ci, co)                                                                                               \
+    if (CI == ci && CO == co) {                                                                                 \
+        LAUNCH(m, "tconv2_fwd_" #ci "_" #co, bytes, flops,                                                      \
+               hipLaunchKernelGGL((k_tconv2_fwd<ci, co>), grid, dim3(256), 0, m->stream, o.inA.d.p, m->p + o.w_off, \
+                                  m->p + o.b_off, o.out.d.p, B, H, W));                                         \
+        return true;                                                                                            \
+    }
+    TCONV_CASES(X)
+#undef X
+    return false;
+}
+
+bool fast_tconv_dgrad(Model* m, int B, Op& o, double bytes, double flops) {
+    const int CI = o.inA.d.C, CO = o.out.d.C, H = o.inA.d.H, W = o.inA.d.W;
+    dim3 grid((B * H * W + 255) / 256);
+#define X(ci, co)                                                                                               \
+    if (CI == ci && CO == co) {                                                                                 \
+        LAUNCH(m, "tconv2_dgrad_" #ci "_" #co, bytes, flops,                                                    \
+               hipLaunchKernelGGL((k_tconv2_dgrad<ci, co>), grid, dim3(256), 0, m->stream, o.out.g.p, m->p + o.w_off, \
+                                  o.inA.d.p, o.inA.g.p, B, H, W, (int)o.accA, (int)o.maskA, o.mask_alpha));     \
+        return true;                                                                                            \
+    }
+    TCONV_CASES(X)
+#undef X
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ fused head (training)
+// feat [B,H,W,C] -> logit = b + sum_c w_c feat_c -> weighted BCE (utils/losses.py:17-37) -> dlogit -> dfeat, dW, db.
+// One thread = 4 pixels.  scalars[0] (label sum) must be complete (k_label_stats ran earlier on the stream).
+struct HeadArgs {
+    const float* feat;
+    const float* y;
+    const float* w;        // C weights + 1 bias (bias at w_bias)
+    const float* bias;
+    float* dfeat;
+    float* dw;             // gradient destinations
+    float* dbias;
+    double* scalars;
+    dnnca_loss_cfg cfg;
+    double n_label;
+    float gscale;
+    int mask;              // multiply dfeat by act'(feat)
+    float alpha;
+    int n4;                // number of 4-pixel chunks
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void k_head_train(HeadArgs p) {
+    __shared__ float red[4][C + 2];
+    float wv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) wv[c] = p.w[c];
+    const float bias = p.bias[0];
+    float wgt;
+    if (p.cfg.has_weight) {
+        wgt = p.cfg.weight;
+    } else {
+        float pr = (float)(p.scalars[0] / p.n_label);
+        wgt = pr > 0.f ? 1.0f / pr : 1.0f;
+    }
+    wgt = p.cfg.weight_mul * wgt + p.cfg.weight_add;
+
+    float sdw[C], sdb = 0.f, sloss = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) sdw[c] = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.n4; i += gridDim.x * 256) {
+        float f[4 * C], z[4], df[4 * C];
+#pragma unroll
+        for (int v = 0; v < C; ++v) ld4(f + 4 * v, p.feat + (size_t)i * 4 * C + 4 * v);
+        ld4(z, p.y + (size_t)i * 4);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            float x = bias;
+#pragma unroll
+            for (int c = 0; c < C; ++c) x = fmaf(f[px * C + c], wv[c], x);
+            const float mk = fmaf(z[px], wgt - 1.0f, 1.0f);
+            const float e = expf(-fabsf(x));
+            sloss = fmaf(fmaxf(x, 0.f) - x * z[px] + log1pf(e), mk, sloss);
+            const float sig = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+            const float dl = mk * (sig - z[px]) * p.gscale;
+            sdb += dl;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float fv = f[px * C + c];
+                sdw[c] = fmaf(fv, dl, sdw[c]);
+                float d = dl * wv[c];
+                if (p.mask) d *= fv > 0.f ? 1.0f : p.alpha;
+                df[px * C + c] = d;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < C; ++v) st4(p.dfeat + (size_t)i * 4 * C + 4 * v, df + 4 * v);
+    }
+    // block reduction: wave shuffles, then 4 partials through LDS, one atomic per value per block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float vals[C + 2];
+#pragma unroll
+    for (int c = 0; c < C; ++c) vals[c] = sdw[c];
+    vals[C] = sdb;
+    vals[C + 1] = sloss;
+#pragma unroll
+    for (int k = 0; k < C + 2; ++k) {
+        float v = vals[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < C + 2) {
+        const int k = threadIdx.x;
+        float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        if (k < C) atomicAdd(p.dw + k, v);
+        else if (k == C) atomicAdd(p.dbias, v);
+        else atomicAdd(p.scalars + 3, (double)v);
+    }
+}
+
+bool fast_head_supported(const Model* m, const Op& o) {
+    return o.type == OP_HEAD && m->desc.dtype == DNNCA_F32 && dense(o.inA.d) && o.inA.d.C == 3 &&
+           ((size_t)o.inA.d.H * o.inA.d.W) % 4 == 0;
+}
+
+bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cfg& cfg, float gscale, double bytes) {
+    if (!fast_head_supported(m, o)) return false;
+    HeadArgs a;
+    a.feat = o.inA.d.p;
+    a.y = y;
+    a.w = m->p + o.w_off;
+    a.bias = m->p + o.b_off;
+    a.dfeat = o.inA.g.p;
+    a.dw = m->g + o.w_off;
+    a.dbias = m->g + o.b_off;
+    a.scalars = m->scalars;
+    a.cfg = cfg;
+    size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
+    a.n_label = (double)npix;
+    a.gscale = gscale;
+    a.mask = o.maskA;
+    a.alpha = o.mask_alpha;
+    a.n4 = (int)(npix / 4);
+    int blocks = (a.n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    LAUNCH(m, "head_train_3", bytes, 30.0 * npix, hipLaunchKernelGGL(k_head_train<3>, dim3(blocks), dim3(256), 0, m->stream, a));
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ label statistics
+__global__ __launch_bounds__(256) void k_label_stats4(int n4, const float* __restrict__ y, double* __restrict__ scalars) {
+    __shared__ float red[4][3];
+    float s = 0.f, mn = INFINITY, mx = -INFINITY;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(y)[i];
+        s += (v.x + v.y) + (v.z + v.w);
+        mn = fminf(fminf(mn, fminf(v.x, v.y)), fminf(v.z, v.w));
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        mn = fminf(mn, __shfl_down(mn, o, 64));
+        mx = fmaxf(mx, __shfl_down(mx, o, 64));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = s;
+        red[wave][1] = mn;
+        red[wave][2] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ds = ((double)red[0][0] + red[1][0]) + ((double)red[2][0] + red[3][0]);
+        float fmn = fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1]));
+        float fmx = fmaxf(fmaxf(red[0][2], red[1][2]), fmaxf(red[2][2], red[3][2]));
+        atomicAdd(scalars + 0, ds);
+        // min / max through compare-and-swap on the double's bits
+        unsigned long long* pmin = (unsigned long long*)(scalars + 1);
+        unsigned long long old = *pmin, assumed;
+        do {
+            assumed = old;
+            if (__longlong_as_double(assumed) <= (double)fmn) break;
+            old = atomicCAS(pmin, assumed, __double_as_longlong((double)fmn));
+        } while (assumed != old);
+        unsigned long long* pmax = (unsigned long long*)(scalars + 2);
+        old = *pmax;
+        do {
+            assumed = old;
+            if (__longlong_as_double(assumed) >= (double)fmx) break;
+            old = atomicCAS(pmax, assumed, __double_as_longlong((double)fmx));
+        } while (assumed != old);
+    }
+}
+
+bool fast_label_stats(Model* m, size_t n, const float* y) {
+    if (n % 4 || n / 4 > 0x7fffffff) return false;
+    int n4 = (int)(n / 4);
+    int blocks = (n4 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    LAUNCH(m, "label_stats4", 4.0 * n, (double)n,
+           hipLaunchKernelGGL(k_label_stats4, dim3(blocks), dim3(256), 0, m->stream, n4, y, m->scalars));
+    return true;
+}
+
+}  // namespace dnnca

@@ -28,6 +28,11 @@ struct Op {
     int k = 0;                           // conv kernel size / pool+tconv rate
     bool need_din = true;                // false for the convs that read the network input
     bool accA = false, accB = false;     // backward: accumulate into (instead of overwrite) the input gradients
+    // activation-derivative fusion: the LAST gradient contributor of a conv+activation output multiplies the summed
+    // gradient by act'(output) when it stores it (maskA/maskB on that consumer), and the producing conv is then
+    // `premasked`: its backward takes out.g as the pre-activation gradient directly.
+    bool maskA = false, maskB = false, premasked = false;
+    float mask_alpha = 0.f;
     float* coef = nullptr;               // BN: [scale, shift, mean, inv] x C
     double* ws = nullptr;                // BN: [sum, centred sumsq] x C
 };
@@ -66,6 +71,7 @@ struct Model {
     int64_t iterations = 0;
     float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f;
     int last_batch = 0;
+    bool defer_head = false, head_deferred = false;   // train step: the head runs fused with the loss and its backward
     // data parallel
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -97,3 +103,18 @@ struct Model {
 };
 
 }  // namespace dnnca
+
+// A launch is only "open" for profiling between begin() and end(); focus mode leaves other launches untouched.
+#define LAUNCH(m, name, bytes, flops, call)                \
+    do {                                                   \
+        bool prof_open_ = false;                           \
+        if ((m)->dry || (m)->prof_mode) {                  \
+            size_t before_ = (m)->recs.size();             \
+            bool go_ = (m)->begin(name, bytes, flops);     \
+            prof_open_ = (m)->recs.size() != before_;      \
+            if (!go_) break;                               \
+        }                                                  \
+        call;                                              \
+        if (prof_open_) (m)->end();                        \
+    } while (0)
+

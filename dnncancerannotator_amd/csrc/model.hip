@@ -29,6 +29,7 @@ static constexpr float kBnMomentum = 0.99f;   // Keras BatchNormalization defaul
 static constexpr float kBnEps = 1e-3f;
 
 Model::~Model() {
+    fast_release(this);
     for (void* a : allocs) (void)hipFree(a);
     for (auto& r : recs) {
         (void)hipEventDestroy(r.a);
@@ -115,20 +116,6 @@ int Model::flush_profile() {
     recs.clear();
     return DNNCA_OK;
 }
-
-// A launch is only "open" for profiling between begin() and end(); focus mode leaves other launches untouched.
-#define LAUNCH(m, name, bytes, flops, call)                \
-    do {                                                   \
-        bool prof_open_ = false;                           \
-        if ((m)->dry || (m)->prof_mode) {                  \
-            size_t before_ = (m)->recs.size();             \
-            bool go_ = (m)->begin(name, bytes, flops);     \
-            prof_open_ = (m)->recs.size() != before_;      \
-            if (!go_) break;                               \
-        }                                                  \
-        call;                                              \
-        if (prof_open_) (m)->end();                        \
-    } while (0)
 
 // ---------------------------------------------------------------------------------------------- plan
 int Model::build() {
@@ -328,6 +315,8 @@ int Model::build() {
         }
     }
 
+    fast_plan_masks(this);
+
     // flat buffers
     DN_TRY(alloc((void**)&p, (size_t)nT * 4));
     DN_TRY(alloc((void**)&g, (size_t)(nT + 8) * 4));
@@ -377,6 +366,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
             o.inA.d.p = const_cast<float*>(x_dev) + off;
         }
     xin.d.p = const_cast<float*>(x_dev);
+    DN_TRY(fast_prepare(this));
 
     for (Op& o : ops) {
         switch (o.type) {
@@ -420,6 +410,11 @@ int Model::forward(const float* x_dev, int B, bool training) {
             }
             case OP_HEAD: {
                 double npix = (double)B * outH * outW;
+                head_deferred = false;
+                if (defer_head && !generic && fast_head_supported(this, o)) {
+                    head_deferred = true;   // runs fused with the loss and its own backward (fast_head_train)
+                    break;
+                }
                 LAUNCH(this, "g_head_fwd", 4.0 * (nelem(B, o.inA.d) + npix), 2.0 * nelem(B, o.inA.d),
                        g_head_fwd(stream, B, o.inA.d, p + o.w_off, p + o.b_off, logits));
                 break;
@@ -436,18 +431,32 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
     // scalars: label sum 0, min +inf, max -inf, loss 0, l2 0
     double init[kScalars] = {0.0, INFINITY, -INFINITY, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (!dry) HIP_TRY(hipMemcpyAsync(scalars, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    LAUNCH(this, "g_label_stats", 4.0 * npix, (double)npix, g_label_stats(stream, npix, y_dev, scalars));
+    if (backward && !dry) HIP_TRY(hipMemsetAsync(g, 0, (size_t)(nT + 8) * 4, stream));
+    if (generic || !fast_label_stats(this, npix, y_dev))
+        LAUNCH(this, "g_label_stats", 4.0 * npix, (double)npix, g_label_stats(stream, npix, y_dev, scalars));
     // dlogits scale: mean over (H, W), then mean over the (rank-local) batch.  Under data parallel every rank uses its
     // local mean; the cross-rank 1/world is applied to the all-reduced gradient in the optimizer step.
     float gscale = (float)(1.0 / ((double)outH * outW * B));
-    LAUNCH(this, "g_loss", 4.0 * npix * (backward ? 4 : 3), 20.0 * npix,
-           g_loss(stream, npix, logits, y_dev, cfg, (double)npix, scalars, backward ? dlogits : nullptr, prob, gscale));
+    bool head_done = false;
+    if (backward && head_deferred) {
+        Op& ho = ops.back();
+        double fb = 4.0 * nelem(B, ho.inA.d);
+        if (!fast_head_train(this, B, ho, y_dev, cfg, gscale, 2 * fb + 4.0 * npix)) {
+            set_error("internal: deferred head has no fused kernel");
+            return DNNCA_ESTATE;
+        }
+        head_done = true;
+    } else {
+        LAUNCH(this, "g_loss", 4.0 * npix * (backward ? 4 : 3), 20.0 * npix,
+               g_loss(stream, npix, logits, y_dev, cfg, (double)npix, scalars, backward ? dlogits : nullptr, prob, gscale));
+    }
     if (backward) {
-        if (!dry) HIP_TRY(hipMemsetAsync(g, 0, (size_t)(nT + 8) * 4, stream));
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             Op& o = ops[i];
             switch (o.type) {
                 case OP_HEAD: {
+                    if (head_done) break;
+                    if (o.maskA) { set_error("internal: masked head gradient needs the fused kernel"); return DNNCA_ESTATE; }
                     double fb = 4.0 * nelem(B, o.inA.d);
                     LAUNCH(this, "g_head_bwd", 2 * fb + 4.0 * npix, 4.0 * nelem(B, o.inA.d),
                            g_head_bwd(stream, B, o.inA.d, p + o.w_off, dlogits, o.inA.g, g + o.w_off, g + o.b_off));
@@ -458,7 +467,8 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d));
                     double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
                     if (!generic && fast_conv_bwd(this, B, o, ob, ib, flops)) break;
-                    if (o.alpha >= 0.f)
+                    if (o.maskA || o.maskB) { set_error("internal: masked conv gradient has no tuned kernel"); return DNNCA_ESTATE; }
+                    if (o.alpha >= 0.f && !o.premasked)
                         LAUNCH(this, "g_act_bwd", 3 * ob, ob / 4,
                                g_act_bwd(stream, (size_t)nelem(B, o.out.d), o.out.g.p, o.out.d.p, o.alpha));
                     LAUNCH(this, "g_conv_wgrad", ob + ib, flops,
@@ -481,6 +491,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 case OP_POOL: {
                     double bytes = 4.0 * (2 * nelem(B, o.inA.d) + 2 * nelem(B, o.out.d));
                     if (!generic && fast_pool_bwd(this, B, o, bytes)) break;
+                    if (o.maskA) { set_error("internal: masked pool gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     LAUNCH(this, "g_pool_bwd", bytes, 0,
                            g_pool_bwd(stream, B, o.inA.d, o.out.d, o.out.g, o.inA.g, o.accA, o.k));
                     break;
@@ -489,6 +500,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * nelem(B, o.inA.d);
                     double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
                     if (!generic && fast_tconv_bwd(this, B, o, ob, ib, flops)) break;
+                    if (o.maskA) { set_error("internal: masked transposed-conv gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     LAUNCH(this, "g_tconv_wgrad", ob + ib, flops,
                            g_tconv_wgrad(stream, B, o.inA.d, o.out.g, g + o.w_off, g + o.b_off, o.k));
                     LAUNCH(this, "g_tconv_dgrad", ob + ib, flops,
@@ -497,6 +509,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 }
             }
         }
+        DN_TRY(fast_finish_backward(this));
         if (desc.l2 > 0.f) {
             for (auto& pi : params) {
                 if (!pi.trainable || pi.name.size() < 7 || pi.name.rfind(".kernel") != pi.name.size() - 7) continue;
@@ -686,7 +699,10 @@ int dnnca_train_step_dev(void* model, const float* x_dev, const float* y_dev, in
                          dnnca_step_out* out) {
     MODEL(model);
     if (!cfg) { set_error("null loss cfg"); return DNNCA_EINVAL; }
-    DN_TRY(M->forward(x_dev, batch, true));
+    M->defer_head = true;
+    int frc = M->forward(x_dev, batch, true);
+    M->defer_head = false;
+    DN_TRY(frc);
     DN_TRY(M->loss_and_backward(y_dev, batch, *cfg, true));
     DN_TRY(M->optimizer_step(lr));
     if (out) return read_out(M, out);
@@ -887,7 +903,9 @@ int dnnca_plan_dump(void* model, char* buf, size_t cap) {
     M->dry = true;
     dnnca_loss_cfg cfg = {0, 0.f, 0.f, 1.f};
     int B = M->desc.max_batch;
+    M->defer_head = true;
     int rc = M->forward(M->x_stage, B, true);
+    M->defer_head = false;
     if (rc == DNNCA_OK) rc = M->loss_and_backward(M->y_stage, B, cfg, true);
     if (rc == DNNCA_OK) rc = M->optimizer_step(1e-3f);
     M->dry = false;

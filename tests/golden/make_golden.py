@@ -40,12 +40,13 @@ CASES = {
     # mulmo structure, small filters
     'mulmo_small_2x16': (dict(arch='mulmo', in_channels=3, n_filters_first=4, n_downsample=2, bn=True, padding='same'),
                          2, 16, 16, dict(weight_mul=3.0), False, True),
-    # configs/mulmo_unet.yaml hyper-parameters (f0 16, 4 levels), 1x32x32x3 (weights regenerated from the seed)
-    'mulmo_yaml_1x32': (dict(arch='mulmo', in_channels=3, n_filters_first=16, n_downsample=4, bn=True, padding='same'),
-                        1, 32, 32, dict(weight_mul=3.0), False, False),
+    # configs/mulmo_unet.yaml hyper-parameters (f0 16, 4 levels), 2x64x64x3 (weights regenerated from the seed);
+    # 64x64 keeps 32 samples per channel in the deepest BatchNorm (a 2x2 bottleneck makes BN ill-conditioned)
+    'mulmo_yaml_2x64': (dict(arch='mulmo', in_channels=3, n_filters_first=16, n_downsample=4, bn=True, padding='same'),
+                        2, 64, 64, dict(weight_mul=3.0), False, False),
     # unet_big.yaml structure (4 levels, BN) at f0 = 8 so the fixture stays small
-    'unet_big_f8_2x32': (dict(arch='unet', in_channels=1, n_filters_first=8, n_downsample=4, bn=True, padding='same'),
-                         2, 32, 32, dict(weight_mul=3.0), False, False),
+    'unet_big_f8_2x64': (dict(arch='unet', in_channels=1, n_filters_first=8, n_downsample=4, bn=True, padding='same'),
+                         2, 64, 64, dict(weight_mul=3.0), False, False),
     # fixed weight (losses.py:24 weight is not None)
     'unet_fixedw_2x16': (dict(arch='unet', in_channels=1, n_filters_first=3, n_downsample=2, bn=False, padding='same'),
                          2, 16, 16, dict(weight=5.0, weight_mul=1.0, weight_add=0.0), False, True),

@@ -9,7 +9,7 @@ from oracle import unet_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 SMALL_CASES = ['unet_yaml_2x32', 'unet_yaml_1x64_nopos', 'unet_bn_leaky_l2_2x16', 'mulmo_small_2x16', 'unet_fixedw_2x16']
-BIG_CASES = ['mulmo_yaml_1x32', 'unet_big_f8_2x32']
+BIG_CASES = ['mulmo_yaml_2x64', 'unet_big_f8_2x64']
 
 
 PARAM_SEED = 2

@@ -61,7 +61,8 @@ def _run_case(gpu, name, force_generic):
             st = int(z['sample_stride'])
             g, pa, gref, paref = g[::st], pa[::st], z['grads_sample'], z['params_after_sample']
             p0 = p0[::st]
-        assert Hp.rel_err(g, gref) <= GRAD_TOL
+        err = Hp.rel_err(g, gref)
+        assert err <= GRAD_TOL, 'gradient max-norm relative error %.3e' % err
         # Adam's first step: |delta| = lr * |g| / (|g| + eps); compare where the gradient is well above rounding noise
         lr = float(z['lr'])
         big = np.abs(gref) > 100 * GRAD_TOL * np.abs(gref).max() * 1e-2
