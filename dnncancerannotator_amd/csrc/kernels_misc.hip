@@ -289,6 +289,7 @@ struct HeadArgs {
     float* dw;             // gradient destinations
     float* dbias;
     double* scalars;
+    float* partials;       // [gridDim.x][C + 2] block partial sums (dW..., db, loss); reduced by k_head_reduce
     dnnca_loss_cfg cfg;
     double n_label;
     float gscale;
@@ -360,10 +361,30 @@ __global__ __launch_bounds__(256) void k_head_train(HeadArgs p) {
     __syncthreads();
     if (threadIdx.x < C + 2) {
         const int k = threadIdx.x;
-        float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-        if (k < C) atomicAdd(p.dw + k, v);
-        else if (k == C) atomicAdd(p.dbias, v);
-        else atomicAdd(p.scalars + 3, (double)v);
+        p.partials[blockIdx.x * (C + 2) + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
+// one block: sums the per-block partials of k_head_train in a fixed order (bit-reproducible) into the gradient vector
+template <int C>
+__global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ partials, int nblocks, float* dw, float* dbias,
+                                                     double* scalars) {
+    __shared__ double red[256];
+    for (int k = 0; k < C + 2; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partials[i * (C + 2) + k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (k < C) dw[k] = (float)red[0];
+            else if (k == C) dbias[0] = (float)red[0];
+            else scalars[3] = red[0];
+        }
+        __syncthreads();
     }
 }
 
@@ -392,7 +413,11 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
     a.n4 = (int)(npix / 4);
     int blocks = (a.n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    a.partials = m->head_partials;
     LAUNCH(m, "head_train_3", bytes, 30.0 * npix, hipLaunchKernelGGL(k_head_train<3>, dim3(blocks), dim3(256), 0, m->stream, a));
+    LAUNCH(m, "head_reduce", 0, 0,
+           hipLaunchKernelGGL(k_head_reduce<3>, dim3(1), dim3(256), 0, m->stream, m->head_partials, blocks, a.dw, a.dbias,
+                              m->scalars));
     return true;
 }
 
@@ -445,7 +470,7 @@ bool fast_label_stats(Model* m, size_t n, const float* y) {
     if (n % 4 || n / 4 > 0x7fffffff) return false;
     int n4 = (int)(n / 4);
     int blocks = (n4 + 255) / 256;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 128) blocks = 128;
     LAUNCH(m, "label_stats4", 4.0 * n, (double)n,
            hipLaunchKernelGGL(k_label_stats4, dim3(blocks), dim3(256), 0, m->stream, n4, y, m->scalars));
     return true;

@@ -332,6 +332,7 @@ int Model::build() {
     DN_TRY(alloc((void**)&dlogits, npix * 4));
     DN_TRY(alloc((void**)&prob, npix * 4));
     DN_TRY(alloc((void**)&thr_dev, 256 * 4));
+    DN_TRY(alloc((void**)&head_partials, 2048 * 8 * 4));
     DN_TRY(alloc((void**)&conf_dev, 256 * 4 * 8));
     // Keras defaults for the non-trainable / BN variables: gamma 1, moving_variance 1 (the rest 0)
     {
@@ -451,6 +452,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                g_loss(stream, npix, logits, y_dev, cfg, (double)npix, scalars, backward ? dlogits : nullptr, prob, gscale));
     }
     if (backward) {
+        DN_TRY(fast_begin_backward(this));
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             Op& o = ops[i];
             switch (o.type) {
