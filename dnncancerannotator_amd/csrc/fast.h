@@ -6,7 +6,6 @@
 namespace dnnca {
 
 int fast_prepare(Model* m);     // per-step operand preparation (weights -> MFMA B operands)
-int fast_begin_backward(Model* m);    // zeroes the weight-gradient partial-sum slabs
 int fast_finish_backward(Model* m);   // folds the weight-gradient slabs into the flat gradient vector
 void fast_release(Model* m);    // drop the per-model plan
 bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops);

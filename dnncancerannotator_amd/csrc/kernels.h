@@ -54,5 +54,7 @@ void g_adam(hipStream_t s, size_t n, float* p, const float* g, float* m, float* 
             float eps, float gscale);
 void g_confusion(hipStream_t s, size_t n, const float* prob, const float* y, const float* thr, int nthr, double* out4);
 void g_scale(hipStream_t s, size_t n, float* p, float a);
+// zeroes a[0..na) and b[0..nb) (either may be empty) and resets the scalar block, in one launch
+void g_step_init(hipStream_t s, double* scalars, float* a, size_t na, float* b, size_t nb);
 
 }  // namespace dnnca

@@ -671,6 +671,29 @@ void g_confusion(hipStream_t s, size_t n, const float* prob, const float* y, con
     hipLaunchKernelGGL(k_confusion, dim3(blocks), dim3(TB), 0, s, n, prob, y, thr, nthr, out4);
 }
 
+// one launch at the top of a step: scalar block, flat gradient vector and the weight-gradient slabs
+__global__ __launch_bounds__(256) void k_step_init(double* __restrict__ scalars, float4* __restrict__ a, size_t na4,
+                                                    float4* __restrict__ b, size_t nb4) {
+    const size_t T = (size_t)gridDim.x * TB;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < na4; i += T) a[i] = z;
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < nb4; i += T) b[i] = z;
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        // label sum 0, min +inf, max -inf, loss 0, l2 0, spare
+        scalars[threadIdx.x] = threadIdx.x == 1 ? (double)INFINITY : (threadIdx.x == 2 ? -(double)INFINITY : 0.0);
+    }
+}
+
+void g_step_init(hipStream_t s, double* scalars, float* a, size_t na, float* b, size_t nb) {
+    size_t na4 = (na + 3) / 4, nb4 = (nb + 3) / 4;   // both buffers are allocated with >= 16 bytes of slack
+    size_t n = na4 + nb4;
+    unsigned blocks = (unsigned)((n + TB * 4 - 1) / (TB * 4));
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_step_init, dim3(blocks), dim3(TB), 0, s, scalars, reinterpret_cast<float4*>(a), na4,
+                       reinterpret_cast<float4*>(b), nb4);
+}
+
 __global__ void k_scale(size_t n, float* __restrict__ p, float a) {
     size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
     if (i < n) p[i] *= a;

@@ -19,6 +19,8 @@
 // cores work on the current one (one LDS buffer, several blocks per CU).
 // exact fp32: the f32 MFMA is a chain of fmaf (MI355X guide, "FP32-input MFMA"), so parity with the oracle holds to
 // fp32 rounding.
+#include <stdlib.h>
+
 #include "fast.h"
 #include "kernels.h"
 
@@ -37,11 +39,11 @@ struct TG {
     static constexpr int LS = (LEAD + (TW + 2) * C + 3 + 3) / 4 * 4;   // LDS row stride (floats)
     static constexpr int LS4 = LS / 4;
     static constexpr int N4 = (TH + 2) * LS4;         // float4's of the staged tile
-    static constexpr int NPF = (N4 + 255) / 256;      // prefetch registers (float4) per thread
+    static constexpr int npf(int nt) { return (N4 + nt - 1) / nt; }   // prefetch registers (float4) per thread
 };
 
 // issue the global loads of one (TH+2)-row halo tile into registers; zero outside the image
-template <int C, int TW>
+template <int C, int TW, int NT>
 __device__ __forceinline__ void tile_issue(float4* pre, const float* __restrict__ src, int b, int x0, int y0, int H, int W,
                                            int tid) {
     using T = TG<C, TW>;
@@ -49,8 +51,8 @@ __device__ __forceinline__ void tile_issue(float4* pre, const float* __restrict_
     const int g40 = (x0 * C - T::HL) / 4;
     const float4* base = reinterpret_cast<const float4*>(src + (size_t)b * H * W * C);
 #pragma unroll
-    for (int k = 0; k < T::NPF; ++k) {
-        const int idx = tid + k * 256;
+    for (int k = 0; k < T::npf(NT); ++k) {
+        const int idx = tid + k * NT;
         const int row = idx / T::LS4, c4 = idx - row * T::LS4;
         const int iy = y0 - 1 + row, g4 = g40 + c4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -59,12 +61,12 @@ __device__ __forceinline__ void tile_issue(float4* pre, const float* __restrict_
     }
 }
 
-template <int C, int TW>
+template <int C, int TW, int NT>
 __device__ __forceinline__ void tile_commit(const float4* pre, float4* lds4, int tid) {
     using T = TG<C, TW>;
 #pragma unroll
-    for (int k = 0; k < T::NPF; ++k) {
-        const int idx = tid + k * 256;
+    for (int k = 0; k < T::npf(NT); ++k) {
+        const int idx = tid + k * NT;
         if (idx < T::N4) lds4[idx] = pre[k];
     }
 }
@@ -80,12 +82,12 @@ struct FwdArgs {
     float alpha;             // activation slope (<0: none)
 };
 
-template <int C, int NSRC, int CO>
-__global__ __launch_bounds__(256) void k_pgfwd(FwdArgs p) {
-    constexpr int G = 12 / CO, TX = 2, TW = 16 * G * TX, N = G * CO;
+template <int C, int NSRC, int CO, int NT>
+__global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
+    constexpr int G = 12 / CO, TX = 2, TW = 16 * G * TX, N = G * CO, NW = NT / 64;
     using T = TG<C, TW>;
     constexpr int WR = (G + 2) * C, SR = (WR + 3) / 4, KS = NSRC * 3 * SR, LS = T::LS;
-    __shared__ float4 lds4[NSRC * T::N4 + 4 * 48];     // staged tiles + one 16x12 output row per wave
+    __shared__ float4 lds4[NSRC * T::N4 + NW * 48];    // staged tiles + one 16x12 output row per wave
     float* lds = reinterpret_cast<float*>(lds4);
     float* orow = reinterpret_cast<float*>(lds4 + NSRC * T::N4) + (threadIdx.x >> 6) * 192;
 
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void k_pgfwd(FwdArgs p) {
     const int co = n % CO;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
 
-    float4 pre[NSRC][T::NPF];
+    float4 pre[NSRC][T::npf(NT)];
     int tile = blockIdx.x;
     auto decode = [&](int t, int& b, int& x0, int& y0) {
         const int bx = t % p.tiles_x, by = (t / p.tiles_x) % p.tiles_y;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void k_pgfwd(FwdArgs p) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_issue<C, TW>(pre[s], p.src[s], b, x0, y0, p.H, p.W, tid);
+        for (int s = 0; s < NSRC; ++s) tile_issue<C, TW, NT>(pre[s], p.src[s], b, x0, y0, p.H, p.W, tid);
     }
     float breg[KS];
 #pragma unroll
@@ -118,47 +120,57 @@ __global__ __launch_bounds__(256) void k_pgfwd(FwdArgs p) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW>(pre[s], lds4 + s * T::N4, tid);
+        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(pre[s], lds4 + s * T::N4, tid);
         __syncthreads();
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
             decode(next, nb, nx0, ny0);
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) tile_issue<C, TW>(pre[s], p.src[s], nb, nx0, ny0, p.H, p.W, tid);
+            for (int s = 0; s < NSRC; ++s) tile_issue<C, TW, NT>(pre[s], p.src[s], nb, nx0, ny0, p.H, p.W, tid);
         }
-#pragma unroll 1
-        for (int t = wave; t < TX * TH; t += 4) {
-            const int tx = t % TX, ty = t / TX;
-            const int y = y0 + ty;
-            if (y >= p.H) break;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // every wave owns NCH = 4 M-tiles (same column block tx, rows ty0 + 2i) and interleaves their MFMA chains:
+        // independent accumulators keep the matrix pipe issuing back to back (a dependent 16x16x4 f32 chain stalls
+        // 8 of every 40 cycles) and put all 60 LDS reads in flight at once
+        {
+            constexpr int NCH = TX * TH / NW;
+            const int tx = wave % TX, ty0 = wave / TX;
+            f32x4 acc[NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int aoff = T::LEAD + (tx * 16 + m) * (G * C) + q;
 #pragma unroll
             for (int s = 0; s < NSRC; ++s)
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const float* ap = lds + s * (T::N4 * 4) + (ty + dy) * LS + aoff;
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int k = 0; k < SR; ++k)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * k], breg[(s * 3 + dy) * SR + k], acc, 0, 0, 0);
-                }
+#pragma unroll
+                        for (int i = 0; i < NCH; ++i) {
+                            const int ty = ty0 + (NW / TX) * i;
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                lds[s * (T::N4 * 4) + (ty + dy) * LS + aoff + 4 * k], breg[(s * 3 + dy) * SR + k], acc[i], 0, 0, 0);
+                        }
             // D[group 4q+r][n] -> the M-tile's output row is 16 groups x 12 contiguous floats: transpose through LDS
             // (same wave writes and reads; DS operations of one wave execute in order) and store 16 B per lane
-            if (n < N) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[r] + bias;
-                    orow[(4 * q + r) * 12 + n] = p.alpha < 0.f ? v : (v > 0.f ? v : p.alpha * v);
+            for (int i = 0; i < NCH; ++i) {
+                const int y = y0 + ty0 + (NW / TX) * i;
+                if (n < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][r] + bias;
+                        orow[(4 * q + r) * 12 + n] = p.alpha < 0.f ? v : (v > 0.f ? v : p.alpha * v);
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();
+                const int f0 = (x0 + tx * 16 * G) * CO + 4 * lane;          // float index within the image row
+                if (lane < 48 && f0 < p.W * CO && y < p.H) {
+                    const float4 v = reinterpret_cast<const float4*>(orow)[lane];
+                    *reinterpret_cast<float4*>(p.dst + ((size_t)b * p.H + y) * p.W * CO + f0) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
-            const int f0 = (x0 + tx * 16 * G) * CO + 4 * lane;          // float index within the image row
-            if (lane < 48 && f0 < p.W * CO) {
-                const float4 v = reinterpret_cast<const float4*>(orow)[lane];
-                *reinterpret_cast<float4*>(p.dst + ((size_t)b * p.H + y) * p.W * CO + f0) = v;
-            }
-            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         tile = next;
@@ -177,6 +189,7 @@ struct BwdArgs {
     int B, H, W;
     int tiles_x, tiles_y;
     float alpha;             // slope of the masked activation
+    int dbg;                 // tuning aid (DNNCA_DBG): bit 0 skip the data-gradient phase, bit 1 skip the weight-gradient phase
 };
 
 template <int C, int NSRC, int CO>
@@ -199,15 +212,16 @@ struct BW {
     static constexpr int LDS4 = STAGE4 > RED4 ? STAGE4 : RED4;
 };
 
-template <int C, int NSRC, int CO, bool DGRAD>
-__global__ __launch_bounds__(256) void k_pgbwd(BwdArgs p) {
+template <int C, int NSRC, int CO, bool DGRAD, int NT>
+__global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
+    constexpr int NW = NT / 64;
     using Wc = BW<C, NSRC, CO>;
     using TGg = typename Wc::TGg;
     using TGx = typename Wc::TGx;
     constexpr int TW = Wc::TW, Gw = Wc::Gw, Gd = Wc::Gd, COd = Wc::COd, NPASS = Wc::NPASS, SRd = Wc::SRd, KSd = Wc::KSd;
     constexpr int MT = Wc::MT, WRw = Wc::WRw, LSg = TGg::LS, LSx = TGx::LS, Nw = Gw * CO, Nd = Gd * COd;
     static_assert(TW % (16 * Gd) == 0, "tile width must hold whole dgrad M-tiles");
-    __shared__ float4 lds4[Wc::LDS4 + 4 * 48];         // staged tiles (reused for the final reduction) + output rows
+    __shared__ float4 lds4[Wc::LDS4 + NW * 48];        // staged tiles (reused for the final reduction) + output rows
     float* gl = reinterpret_cast<float*>(lds4);
     float* xl = reinterpret_cast<float*>(lds4 + TGg::N4);
     float* orow = reinterpret_cast<float*>(lds4 + Wc::LDS4) + (threadIdx.x >> 6) * 192;
@@ -244,8 +258,8 @@ __global__ __launch_bounds__(256) void k_pgbwd(BwdArgs p) {
     // dgrad epilogue: column n = (dxp, co) of pass ps -> (source, channel)
     const int dxp = n / COd, cod = n % COd;
 
-    float4 preg[TGg::NPF];
-    float4 prex[NSRC][TGx::NPF];
+    float4 preg[TGg::npf(NT)];
+    float4 prex[NSRC][TGx::npf(NT)];
     auto decode = [&](int t, int& b, int& x0, int& y0) {
         const int bx = t % p.tiles_x, by = (t / p.tiles_x) % p.tiles_y;
         b = t / (p.tiles_x * p.tiles_y);
@@ -256,63 +270,74 @@ __global__ __launch_bounds__(256) void k_pgbwd(BwdArgs p) {
     if (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
-        tile_issue<CO, TW>(preg, p.dz, b, x0, y0, p.H, p.W, tid);
+        tile_issue<CO, TW, NT>(preg, p.dz, b, x0, y0, p.H, p.W, tid);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_issue<C, TW>(prex[s], p.x[s], b, x0, y0, p.H, p.W, tid);
+        for (int s = 0; s < NSRC; ++s) tile_issue<C, TW, NT>(prex[s], p.x[s], b, x0, y0, p.H, p.W, tid);
     }
 
 #pragma unroll 1
     while (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
-        tile_commit<CO, TW>(preg, lds4, tid);
+        tile_commit<CO, TW, NT>(preg, lds4, tid);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW>(prex[s], lds4 + TGg::N4 + s * TGx::N4, tid);
+        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(prex[s], lds4 + TGg::N4 + s * TGx::N4, tid);
         __syncthreads();
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
             decode(next, nb, nx0, ny0);
-            tile_issue<CO, TW>(preg, p.dz, nb, nx0, ny0, p.H, p.W, tid);
+            tile_issue<CO, TW, NT>(preg, p.dz, nb, nx0, ny0, p.H, p.W, tid);
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) tile_issue<C, TW>(prex[s], p.x[s], nb, nx0, ny0, p.H, p.W, tid);
+            for (int s = 0; s < NSRC; ++s) tile_issue<C, TW, NT>(prex[s], p.x[s], nb, nx0, ny0, p.H, p.W, tid);
         }
 
         // ---- data gradient: conv of dz with the flipped kernel; M-tiles of 16 groups x Gd pixels
-        if (DGRAD) {
+        if (DGRAD && !(p.dbg & 1)) {
+            // M-tiles of this wave: t = wave + 4j, j < MTX*TH/4; NCH of them are processed with interleaved MFMA chains
+            constexpr int PERW = Wc::MTX * TH / NW;
+            constexpr int NCH = PERW >= 4 ? 4 : PERW;
 #pragma unroll 1
-            for (int t = wave; t < Wc::MTX * TH; t += 4) {
-                const int tx = t % Wc::MTX, ty = t / Wc::MTX;
-                const int y = y0 + ty;
-                if (y >= p.H) break;
-                const int aoff = TGg::LEAD + (tx * 16 + m16) * (Gd * CO) + q;
+            for (int j0 = 0; j0 < PERW; j0 += NCH) {
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
-                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 d[NCH];
+                    int txs[NCH], tys[NCH];
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const float* ap = gl + (ty + dy) * LSg + aoff;
+                    for (int i = 0; i < NCH; ++i) {
+                        const int t = wave + NW * (j0 + i);
+                        txs[i] = t % Wc::MTX;
+                        tys[i] = t / Wc::MTX;
+                        d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                         for (int k = 0; k < SRd; ++k)
-                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * k], breg[ps * KSd + dy * SRd + k], d, 0, 0, 0);
-                    }
-                    // transpose D through LDS: per source the M-tile's gradient row is 16 groups x (Gd*Cs) contiguous
-                    // floats (Cs = that source's share of the COd channels); then 16-byte masked/accumulated stores
+#pragma unroll
+                            for (int i = 0; i < NCH; ++i)
+                                d[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    gl[(tys[i] + dy) * LSg + TGg::LEAD + (txs[i] * 16 + m16) * (Gd * CO) + q + 4 * k],
+                                    breg[ps * KSd + dy * SRd + k], d[i], 0, 0, 0);
+                    // transpose D through LDS: per destination the M-tile's gradient row is 16 groups x (Gd*CS)
+                    // contiguous floats; then 16-byte masked / accumulated stores
                     constexpr int SPL = (NSRC == 2 && NPASS == 1) ? 2 : 1;     // destinations covered by this pass
                     constexpr int CS = COd / SPL;                              // channels per destination (== C)
-                    if (n < Nd) {
-                        const int sp = cod / CS, cs = cod - sp * CS;
+                    constexpr int PER4 = 16 * Gd * CS / 4;                      // float4's per destination row segment
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            orow[sp * (16 * Gd * CS) + (4 * q + r) * (Gd * CS) + dxp * CS + cs] = d[r];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    {
-                        constexpr int PER4 = 16 * Gd * CS / 4;                  // float4's per destination row segment
+                    for (int i = 0; i < NCH; ++i) {
+                        const int tx = txs[i], ty = tys[i], y = y0 + ty;
+                        if (n < Nd) {
+                            const int sp = cod / CS, cs = cod - sp * CS;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                orow[sp * (16 * Gd * CS) + (4 * q + r) * (Gd * CS) + dxp * CS + cs] = d[i][r];
+                        }
+                        __builtin_amdgcn_wave_barrier();
                         const int sp = lane / PER4, i4 = lane - sp * PER4;
                         const int src = NPASS == 2 ? ps : sp;
                         const int f0 = (x0 + tx * 16 * Gd) * C + 4 * i4;        // float index within the image row
-                        if (lane < SPL * PER4 && f0 < p.W * C) {
+                        if (lane < SPL * PER4 && f0 < p.W * C && y < p.H) {
                             float4 v = reinterpret_cast<const float4*>(orow)[lane];
                             float* dst = p.dx[src] + ((size_t)b * p.H + y) * p.W * C + f0;
                             if (p.acc[src]) {
@@ -329,14 +354,14 @@ __global__ __launch_bounds__(256) void k_pgbwd(BwdArgs p) {
                             }
                             *reinterpret_cast<float4*>(dst) = v;
                         }
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
         // ---- weight gradient: K = pixel groups (4 per MFMA); every wave takes rows ty = wave, wave + 4
 #pragma unroll 1
-        for (int ty = wave; ty < TH; ty += 4) {
+        for (int ty = (p.dbg & 2) ? TH : wave; ty < TH; ty += NW) {
             const float* gr = gl + (ty + 1) * LSg + TGg::HL + q * Nw + n;
 #pragma unroll
             for (int st = 0; st < TW / (4 * Gw); ++st) {
@@ -359,15 +384,37 @@ __global__ __launch_bounds__(256) void k_pgbwd(BwdArgs p) {
     // ---- sum the 4 waves through LDS; the block adds its partial D into slab (blockIdx % NBUCKET)
     float* red = reinterpret_cast<float*>(lds4);
     constexpr int PER = NSRC * MT * 256;
+    if (NW == 8) {      // waves 4..7 hand their sums to waves 0..3 first (the LDS holds four partial sets)
+        if (wave >= 4) {
 #pragma unroll
-    for (int s = 0; s < NSRC; ++s)
+            for (int s = 0; s < NSRC; ++s)
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+                for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave * PER + ((s * MT + t) * 4 + r) * 64 + lane] = acc[s][t][r];
+                    for (int r = 0; r < 4; ++r) red[(wave - 4) * PER + ((s * MT + t) * 4 + r) * 64 + lane] = acc[s][t][r];
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[s][t][r] += red[wave * PER + ((s * MT + t) * 4 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave < 4) {
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * PER + ((s * MT + t) * 4 + r) * 64 + lane] = acc[s][t][r];
+    }
     __syncthreads();
     const int bucket = blockIdx.x % NBUCKET;
-    for (int i = tid; i < PER; i += 256) {
+    for (int i = tid; i < PER; i += NT) {
         const float v = (red[i] + red[PER + i]) + (red[2 * PER + i] + red[3 * PER + i]);
         const int s = i / (MT * 256), e = i - s * (MT * 256);
         atomicAdd(p.slabs[s] + (size_t)bucket * (MT * 256) + e, v);
@@ -383,29 +430,38 @@ struct PrepDesc {
     int cin_total, cout_total, o_off;
 };
 
-__global__ void k_pg_prep(const PrepDesc* __restrict__ descs, const float* __restrict__ params, float* __restrict__ bmat) {
+// the (static) gather table: for every B-operand element the index of its weight in the parameter vector, or -1
+__global__ void k_pg_prep_index(const PrepDesc* __restrict__ descs, int* __restrict__ index) {
     const PrepDesc d = descs[blockIdx.x];
     const int WR = (d.G + 2) * d.C, SR = (WR + 3) / 4;
     const int KS = d.NSRC * 3 * SR;
-    const float* w = params + d.w_off;
     for (int i = threadIdx.x; i < KS * 64; i += blockDim.x) {
         int lane = i & 63, step = i >> 6;
         int n = lane & 15, kk = lane >> 4;
         int s = step / (3 * SR), dy = (step / SR) % 3, k = step % SR;
         int j = 4 * k + kk;
-        float v = 0.f;
+        int v = -1;
         if (j < WR && n < d.G * d.CO) {
             int xoff = j / d.C, ci = j % d.C, dx = n / d.CO, co = n % d.CO;
             int kx = xoff - dx;
             if (kx >= 0 && kx <= 2) {
                 if (d.mode == 0)
-                    v = w[((dy * 3 + kx) * d.cin_total + s * d.C + ci) * d.cout_total + co];
+                    v = d.w_off + ((dy * 3 + kx) * d.cin_total + s * d.C + ci) * d.cout_total + co;
                 else
-                    v = w[(((2 - dy) * 3 + (2 - kx)) * d.cin_total + d.o_off + co) * d.cout_total + ci];
+                    v = d.w_off + (((2 - dy) * 3 + (2 - kx)) * d.cin_total + d.o_off + co) * d.cout_total + ci;
             }
         }
-        bmat[d.out_off + i] = v;
+        index[d.out_off + i] = v;
     }
+}
+
+// every step: B operands <- current weights (a plain gather)
+__global__ __launch_bounds__(256) void k_pg_prep(const int* __restrict__ index, const float* __restrict__ params,
+                                                 float* __restrict__ bmat, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = index[i];
+    bmat[i] = j >= 0 ? params[j] : 0.f;
 }
 
 // ================================================================================================ fold
@@ -428,17 +484,21 @@ __global__ __launch_bounds__(256) void k_pg_fold(const FoldDesc* __restrict__ de
                                                  float* __restrict__ grads) {
     __shared__ float Dl[7 * 256];
     const FoldDesc d = descs[blockIdx.x];
+    {
+        const int total = d.kind == 1 ? 4 * d.CO * d.C + d.CO : 9 * d.C * d.CO + (d.b_off >= 0 ? d.CO : 0);
+        if ((int)(blockIdx.y * blockDim.x) >= total) return;     // block-uniform
+    }
     const float* S = slabs + d.slab_off;
     const int stride = d.MT * 256;
     for (int i = threadIdx.x; i < stride; i += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int s = 0; s < d.nslabs; s += 4) {
-            a0 += S[(size_t)s * stride + i];
-            a1 += S[(size_t)(s + 1) * stride + i];
-            a2 += S[(size_t)(s + 2) * stride + i];
-            a3 += S[(size_t)(s + 3) * stride + i];
-        }
-        Dl[i] = (a0 + a1) + (a2 + a3);
+        float v[NBUCKET];
+#pragma unroll
+        for (int s = 0; s < NBUCKET; ++s) v[s] = S[(size_t)s * stride + i];      // all slabs in flight at once
+#pragma unroll
+        for (int w = NBUCKET / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int s = 0; s < w; ++s) v[s] += v[s + w];
+        Dl[i] = v[0];
     }
     __syncthreads();
     const int o = blockIdx.y * blockDim.x + threadIdx.x;
@@ -503,16 +563,24 @@ __global__ __launch_bounds__(256) void k_tconv_wgrad(TwArgs p) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    for (int quad = gw; quad < p.nquads; quad += nw) {
-        const int pix = quad * 4 + q;
-        const int j = pix % p.W, bi = pix / p.W;
-        const float bv = n < CIN ? p.in[(size_t)pix * CIN + n] : (n == CIN ? 1.0f : 0.0f);
-        const float* dp = p.dout + ((size_t)bi * 2 * (2 * p.W) + 2 * j) * COUT;
+    constexpr int UQ = 4;          // quads per iteration: all their loads are in flight before the first MFMA
+    for (int quad0 = gw * UQ; quad0 < p.nquads; quad0 += nw * UQ) {
+        float av[UQ][MT], bv[UQ];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const float av = valid[t] ? dp[aoff[t]] : 0.0f;
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+        for (int u = 0; u < UQ; ++u) {
+            const int quad = quad0 + u;
+            const bool ok = quad < p.nquads;
+            const int pix = (ok ? quad : 0) * 4 + q;
+            const int j = pix % p.W, bi = pix / p.W;
+            bv[u] = !ok ? 0.0f : (n < CIN ? p.in[(size_t)pix * CIN + n] : (n == CIN ? 1.0f : 0.0f));
+            const float* dp = p.dout + ((size_t)bi * 2 * (2 * p.W) + 2 * j) * COUT;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) av[u][t] = (ok && valid[t]) ? dp[aoff[t]] : 0.0f;
         }
+#pragma unroll
+        for (int u = 0; u < UQ; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t], bv[u], acc[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -530,6 +598,8 @@ struct PgPlan {                      // per-model table built lazily on the firs
     std::vector<PrepDesc> descs;
     PrepDesc* descs_dev = nullptr;
     float* bmat = nullptr;
+    int* bindex = nullptr;
+    int bmat_n = 0;
     std::map<std::pair<const Op*, int>, int> slot;   // (op, kind) -> bmat offset;  kind 0 fwd, 1 dgrad (all passes)
     std::vector<FoldDesc> folds;
     FoldDesc* folds_dev = nullptr;
@@ -537,7 +607,8 @@ struct PgPlan {                      // per-model table built lazily on the firs
     size_t slab_floats = 0;
     std::map<std::pair<const Op*, int>, int> wslot;  // (op, source) -> index into folds (transposed convs: source 0)
     int fold_chunks = 0;
-    int nblocks_cap = 768;
+    int nblocks_cap = 512;
+    int nthreads = 512;
 };
 
 static std::map<Model*, PgPlan> g_plans;
@@ -624,18 +695,25 @@ static int build_plan(Model* m, PgPlan& pl) {
         if (outs > max_out) max_out = outs;
     }
     pl.built = true;
+    if (const char* e = getenv("DNNCA_NT")) pl.nthreads = atoi(e) == 256 ? 256 : 512;   // tuning aid
+    if (const char* e = getenv("DNNCA_NBLOCKS")) pl.nblocks_cap = atoi(e) > 0 ? atoi(e) : pl.nblocks_cap;   // tuning aid
     if (pl.folds.empty() && pl.descs.empty()) return DNNCA_OK;
     pl.fold_chunks = (max_out + 255) / 256;
     pl.slab_floats = slab_floats;
     if (!pl.folds.empty()) {
         DN_TRY(m->alloc((void**)&pl.folds_dev, pl.folds.size() * sizeof(FoldDesc)));
-        DN_TRY(m->alloc((void**)&pl.slabs, slab_floats * 4));
+        DN_TRY(m->alloc((void**)&pl.slabs, (slab_floats + 4) * 4));
+        m->extra_zero = pl.slabs;           // accumulated with atomics: model.hip zeroes them at the top of each backward
+        m->extra_zero_n = slab_floats;
         HIP_TRY(hipMemcpyAsync(pl.folds_dev, pl.folds.data(), pl.folds.size() * sizeof(FoldDesc), hipMemcpyHostToDevice, m->stream));
     }
     if (!pl.descs.empty()) {
         DN_TRY(m->alloc((void**)&pl.descs_dev, pl.descs.size() * sizeof(PrepDesc)));
         DN_TRY(m->alloc((void**)&pl.bmat, (size_t)off * 4));
+        DN_TRY(m->alloc((void**)&pl.bindex, (size_t)off * 4));
+        pl.bmat_n = off;
         HIP_TRY(hipMemcpyAsync(pl.descs_dev, pl.descs.data(), pl.descs.size() * sizeof(PrepDesc), hipMemcpyHostToDevice, m->stream));
+        hipLaunchKernelGGL(k_pg_prep_index, dim3((unsigned)pl.descs.size()), dim3(256), 0, m->stream, pl.descs_dev, pl.bindex);
     }
     HIP_TRY(hipStreamSynchronize(m->stream));
     return DNNCA_OK;
@@ -648,16 +726,8 @@ int fast_prepare(Model* m) {
     if (!pl.built) DN_TRY(build_plan(m, pl));
     if (pl.descs.empty()) return DNNCA_OK;
     LAUNCH(m, "pg_prep", 0, 0,
-           hipLaunchKernelGGL(k_pg_prep, dim3((unsigned)pl.descs.size()), dim3(256), 0, m->stream, pl.descs_dev, m->p, pl.bmat));
-    return DNNCA_OK;
-}
-
-// Called at the top of every backward pass: the weight-gradient slabs are accumulated with atomics.
-int fast_begin_backward(Model* m) {
-    if (m->desc.flags & 1) return DNNCA_OK;
-    PgPlan& pl = g_plans[m];
-    if (!pl.built || pl.folds.empty() || m->dry) return DNNCA_OK;
-    HIP_TRY(hipMemsetAsync(pl.slabs, 0, pl.slab_floats * 4, m->stream));
+           hipLaunchKernelGGL(k_pg_prep, dim3((pl.bmat_n + 255) / 256), dim3(256), 0, m->stream, pl.bindex, m->p, pl.bmat,
+                              pl.bmat_n));
     return DNNCA_OK;
 }
 
@@ -683,8 +753,12 @@ bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
     int nb = ntiles < pl.nblocks_cap ? ntiles : pl.nblocks_cap;
 #define X(c, ns, co)                                                                                            \
     if (C == c && NS == ns && CO == co) {                                                                       \
-        LAUNCH(m, "pgfwd_" #c "x" #ns "_" #co, bytes, flops,                                                    \
-               hipLaunchKernelGGL((k_pgfwd<c, ns, co>), dim3(nb), dim3(256), 0, m->stream, a));                 \
+        if (pl.nthreads == 256)                                                                                 \
+            LAUNCH(m, "pgfwd_" #c "x" #ns "_" #co, bytes, flops,                                                \
+                   hipLaunchKernelGGL((k_pgfwd<c, ns, co, 256>), dim3(nb), dim3(256), 0, m->stream, a));        \
+        else                                                                                                    \
+            LAUNCH(m, "pgfwd_" #c "x" #ns "_" #co, bytes, flops,                                                \
+                   hipLaunchKernelGGL((k_pgfwd<c, ns, co, 512>), dim3(nb), dim3(512), 0, m->stream, a));        \
         return true;                                                                                            \
     }
     CONV_SHAPES(X)
@@ -712,6 +786,7 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     a.acc[0] = o.accA; a.acc[1] = o.accB;
     a.mask[0] = o.maskA; a.mask[1] = o.maskB;
     a.alpha = o.mask_alpha;
+    if (const char* e = getenv("DNNCA_DBG")) a.dbg = atoi(e);
     for (int s = 0; s < NS; ++s) {
         auto it = pl.wslot.find({&o, s});
         if (it == pl.wslot.end()) return false;
@@ -727,12 +802,18 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     const double fl = (o.need_din ? 2 : 1) * flops;
 #define X(c, ns, co)                                                                                            \
     if (C == c && NS == ns && CO == co) {                                                                       \
-        if (o.need_din)                                                                                         \
+        if (o.need_din && pl.nthreads == 256)                                                                   \
             LAUNCH(m, "pgbwd_" #c "x" #ns "_" #co, bytes, fl,                                                   \
-                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, true>), dim3(nb), dim3(256), 0, m->stream, a));       \
+                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, true, 256>), dim3(nb), dim3(256), 0, m->stream, a));  \
+        else if (o.need_din)                                                                                    \
+            LAUNCH(m, "pgbwd_" #c "x" #ns "_" #co, bytes, fl,                                                   \
+                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, true, 512>), dim3(nb), dim3(512), 0, m->stream, a));  \
+        else if (pl.nthreads == 256)                                                                            \
+            LAUNCH(m, "pgbwd_w_" #c "x" #ns "_" #co, bytes, fl,                                                 \
+                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, false, 256>), dim3(nb), dim3(256), 0, m->stream, a)); \
         else                                                                                                    \
             LAUNCH(m, "pgbwd_w_" #c "x" #ns "_" #co, bytes, fl,                                                 \
-                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, false>), dim3(nb), dim3(256), 0, m->stream, a));      \
+                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, false, 512>), dim3(nb), dim3(512), 0, m->stream, a)); \
         return true;                                                                                            \
     }
     CONV_SHAPES(X)

@@ -370,7 +370,8 @@ template <int C>
 __global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ partials, int nblocks, float* dw, float* dbias,
                                                      double* scalars) {
     __shared__ double red[256];
-    for (int k = 0; k < C + 2; ++k) {
+    {
+        const int k = blockIdx.x;       // one block per reduced value
         double s = 0.0;
         for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partials[i * (C + 2) + k];
         red[threadIdx.x] = s;
@@ -416,7 +417,7 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
     a.partials = m->head_partials;
     LAUNCH(m, "head_train_3", bytes, 30.0 * npix, hipLaunchKernelGGL(k_head_train<3>, dim3(blocks), dim3(256), 0, m->stream, a));
     LAUNCH(m, "head_reduce", 0, 0,
-           hipLaunchKernelGGL(k_head_reduce<3>, dim3(1), dim3(256), 0, m->stream, m->head_partials, blocks, a.dw, a.dbias,
+           hipLaunchKernelGGL(k_head_reduce<3>, dim3(3 + 2), dim3(256), 0, m->stream, m->head_partials, blocks, a.dw, a.dbias,
                               m->scalars));
     return true;
 }
@@ -425,11 +426,21 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
 __global__ __launch_bounds__(256) void k_label_stats4(int n4, const float* __restrict__ y, double* __restrict__ scalars) {
     __shared__ float red[4][3];
     float s = 0.f, mn = INFINITY, mx = -INFINITY;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
-        float4 v = reinterpret_cast<const float4*>(y)[i];
-        s += (v.x + v.y) + (v.z + v.w);
-        mn = fminf(fminf(mn, fminf(v.x, v.y)), fminf(v.z, v.w));
-        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    const int T = gridDim.x * 256;
+    for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 8 * T) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {      // 8 independent 16-byte loads in flight per thread
+            const int i = i0 + u * T;
+            v[u] = i < n4 ? reinterpret_cast<const float4*>(y)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u * T >= n4) continue;
+            s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            mn = fminf(fminf(mn, fminf(v[u].x, v[u].y)), fminf(v[u].z, v[u].w));
+            mx = fmaxf(fmaxf(mx, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_down(s, o, 64);
@@ -470,7 +481,7 @@ bool fast_label_stats(Model* m, size_t n, const float* y) {
     if (n % 4 || n / 4 > 0x7fffffff) return false;
     int n4 = (int)(n / 4);
     int blocks = (n4 + 255) / 256;
-    if (blocks > 128) blocks = 128;
+    if (blocks > 256) blocks = 256;
     LAUNCH(m, "label_stats4", 4.0 * n, (double)n,
            hipLaunchKernelGGL(k_label_stats4, dim3(blocks), dim3(256), 0, m->stream, n4, y, m->scalars));
     return true;

@@ -319,7 +319,7 @@ int Model::build() {
 
     // flat buffers
     DN_TRY(alloc((void**)&p, (size_t)nT * 4));
-    DN_TRY(alloc((void**)&g, (size_t)(nT + 8) * 4));
+    DN_TRY(alloc((void**)&g, (size_t)(nT + 8 + 4) * 4));
     DN_TRY(alloc((void**)&m, (size_t)nT * 4));
     DN_TRY(alloc((void**)&v, (size_t)nT * 4));
     DN_TRY(alloc((void**)&state, (size_t)nS * 4));
@@ -430,9 +430,9 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
     const bool generic = desc.flags & 1;
     size_t npix = (size_t)B * outH * outW;
     // scalars: label sum 0, min +inf, max -inf, loss 0, l2 0
-    double init[kScalars] = {0.0, INFINITY, -INFINITY, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (!dry) HIP_TRY(hipMemcpyAsync(scalars, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    if (backward && !dry) HIP_TRY(hipMemsetAsync(g, 0, (size_t)(nT + 8) * 4, stream));
+    LAUNCH(this, "g_step_init", 0, 0,
+           g_step_init(stream, scalars, g, backward ? (size_t)(nT + 8) : 0, extra_zero,
+                       backward && !generic ? extra_zero_n : 0));
     if (generic || !fast_label_stats(this, npix, y_dev))
         LAUNCH(this, "g_label_stats", 4.0 * npix, (double)npix, g_label_stats(stream, npix, y_dev, scalars));
     // dlogits scale: mean over (H, W), then mean over the (rank-local) batch.  Under data parallel every rank uses its
@@ -452,7 +452,6 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                g_loss(stream, npix, logits, y_dev, cfg, (double)npix, scalars, backward ? dlogits : nullptr, prob, gscale));
     }
     if (backward) {
-        DN_TRY(fast_begin_backward(this));
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             Op& o = ops[i];
             switch (o.type) {
@@ -895,6 +894,21 @@ int dnnca_profile_get(void* model, int index, char* name, size_t name_cap, int64
     double L = k.launches ? (double)k.launches : 1.0;
     if (algorithmic_bytes) *algorithmic_bytes = k.bytes / L;
     if (flops) *flops = k.flops / L;
+    return DNNCA_OK;
+}
+
+// development aid (not part of include/dnnca.h): n back-to-back launches of a trivial kernel on the model's stream
+__global__ void k_noop(float* p) { if (p == nullptr) *p = 0.f; }
+int dnnca_debug_launch_cost(void* model, int n, int blocks, float* us_per_launch) {
+    MODEL(model);
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    HIP_TRY(hipEventRecord(M->ev0, M->stream));
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_noop, dim3(blocks), dim3(256), 0, M->stream, M->prob);
+    HIP_TRY(hipEventRecord(M->ev1, M->stream));
+    HIP_TRY(hipEventSynchronize(M->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, M->ev0, M->ev1));
+    *us_per_launch = ms * 1000.f / n;
     return DNNCA_OK;
 }
 
