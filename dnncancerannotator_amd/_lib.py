@@ -86,6 +86,7 @@ SIGNATURES = {
     'dnnca_comm_unique_id': (C.c_int, [_VP]),
     'dnnca_comm_init': (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_size_t]),
     'dnnca_comm_world': (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'dnnca_comm_broadcast_weights': (C.c_int, [_VP, C.c_int]),
     'dnnca_comm_average_state': (C.c_int, [_VP]),
     'dnnca_comm_allreduce_host': (C.c_int, [_VP, _FP, C.c_int, C.c_int]),
     'dnnca_timer_start': (C.c_int, [_VP]),

@@ -817,6 +817,19 @@ int dnnca_comm_world(void* model, int* rank, int* world) {
     return DNNCA_OK;
 }
 
+int dnnca_comm_broadcast_weights(void* model, int root) {
+    MODEL(model);
+    if (M->world == 1) return DNNCA_OK;
+    struct { float* p; int64_t n; } bufs[4] = {{M->p, M->nT}, {M->state, M->nS}, {M->m, M->nT}, {M->v, M->nT}};
+    for (auto& b : bufs) {
+        if (b.n == 0) continue;
+        ncclResult_t r = ncclBroadcast(b.p, b.p, (size_t)b.n, ncclFloat, root, M->comm, M->stream);
+        if (r != ncclSuccess) { set_error("ncclBroadcast: %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
+    }
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    return DNNCA_OK;
+}
+
 int dnnca_comm_average_state(void* model) {
     MODEL(model);
     if (M->world == 1 || M->nS == 0) return DNNCA_OK;

@@ -237,6 +237,9 @@ class DeviceModel:
     def comm_init(self, rank, world, unique_id):
         check(self.lib.dnnca_comm_init(self.handle, int(rank), int(world), unique_id, len(unique_id) if unique_id else 0))
 
+    def comm_broadcast_weights(self, root=0):
+        check(self.lib.dnnca_comm_broadcast_weights(self.handle, int(root)))
+
     def comm_average_state(self):
         check(self.lib.dnnca_comm_average_state(self.handle))
 

@@ -1,0 +1,305 @@
+"""Engine facade: the MI355X stand-in for annotator/engine.py:36-288 (class TFKerasModel).
+
+Same constructor, same methods (train / eval / predict / save / load / get_ckpts / get_config), same save-directory
+layout (checkpoints/ckpt-{step}.index, options.yaml, results.csv); underneath, a DeviceModel (libdnnca, hand-written HIP)
+instead of a compiled tf.keras.Model.  One Keras "epoch" of the reference is one optimizer step (engine.py:126-135), so
+the loop here is a plain step loop.
+
+Data parallel (deploy_options.enable_multigpu, engine.py:260-263): one process per GPU.  Each rank takes its contiguous
+shard of every global batch, libdnnca sums the gradients with one RCCL all-reduce per step, rank 0 writes files.
+Ranks come from RANK / LOCAL_RANK / WORLD_SIZE (set by `python -m dnncancerannotator_amd.launch` or torchrun)."""
+
+import copy
+import json
+import logging
+import os
+import re
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from . import device, distributed, losses as custom_losses, metrics as custom_metrics, models
+
+
+class History:
+    """The part of keras.callbacks.History that utils/dump.py:68-73 reads."""
+
+    def __init__(self, model):
+        self.epoch = []
+        self.history = {}
+        self.params = {}
+        self.model = model
+
+    def log(self, step, logs):
+        self.epoch.append(step)
+        for k, v in logs.items():
+            self.history.setdefault(k, []).append(v)
+
+
+def _element_shape(dataset):
+    """Input shape [B, H, W, C] of a dataset: `element_spec[0].shape` (engine.py:93) or, failing that, its first batch."""
+    spec = getattr(dataset, 'element_spec', None)
+    if spec is not None:
+        return tuple(spec[0].shape)
+    for x, _ in dataset:
+        return tuple(np.shape(x))
+    raise ValueError('empty dataset')
+
+
+class TFKerasModel:
+    """Encapsulates the DNN model and the library behind it (name kept from the reference for drop-in use)."""
+
+    def __init__(self, model_config):
+        self.model_config = copy.deepcopy(model_config)
+        self.ctx = distributed.context()
+        self.model = self.from_config(model_config)
+        self.current_step = 0
+        self.ckpt_pattern = 'ckpt-{epoch}'
+        self.device_model = None
+
+    # ---- construction (engine.py:254-288) --------------------------------------------------------------------
+    def from_config(self, model_config):
+        assert 'model' in model_config
+        assert 'model_options' in model_config
+        assert 'deploy_options' in model_config
+        deploy = copy.deepcopy(model_config['deploy_options'])
+        self.enable_multigpu = deploy.pop('enable_multigpu', True)
+        if not self.enable_multigpu and self.ctx.world > 1:
+            raise ValueError('enable_multigpu is false but WORLD_SIZE is %d' % self.ctx.world)
+        if self.enable_multigpu and self.ctx.world == 1 and device.device_count() > 1 and self.ctx.rank == 0:
+            logging.warning('enable_multigpu: %d GPUs visible but one process; launch with '
+                            '`python -m dnncancerannotator_amd.launch --nproc N ...` for data parallel', device.device_count())
+        self.learning_rate_scheduler = deploy.pop('LearningRateScheduler', None)
+        model = getattr(models, model_config['model'])(**model_config['model_options'])
+        self.loss = custom_losses.get(deploy['loss']) if 'loss' in deploy else custom_losses.WeightedCrossentropy()
+        self.metrics = [m for m in map(custom_metrics.solve_metric, deploy.get('metrics', [])) if m is not None]
+        if deploy.get('optimizer') != 'adam':
+            raise NotImplementedError('only the reference\'s optimizer: adam is supported (engine.py:276-284)')
+        self.learning_rate = 0.001          # engine.py:278
+        self.adam = dict(beta1=0.9, beta2=0.999, epsilon=1e-7)
+        return model
+
+    def _build(self, dataset, max_batch=None):
+        if self.device_model is not None:
+            return
+        shape = _element_shape(dataset)
+        global_batch = max_batch or shape[0]
+        if global_batch is None:
+            raise ValueError('dataset batch size unknown')
+        if global_batch % self.ctx.world:
+            raise ValueError('global batch %d is not divisible by %d ranks' % (global_batch, self.ctx.world))
+        device.init_device(self.ctx.local_rank)
+        self.device_model = self.model.build([global_batch // self.ctx.world] + list(shape[1:]), seed=0)
+        self.device_model.set_adam(**self.adam)
+        if self.ctx.world > 1:
+            self.device_model.comm_init(self.ctx.rank, self.ctx.world, distributed.exchange_unique_id(self.ctx, device.DeviceModel))
+            # identical initial weights on every replica (MirroredStrategy mirrors rank 0's variables)
+            self.device_model.comm_broadcast_weights(0)
+
+    def _shard(self, x, y=None):
+        """Contiguous shard of a global batch for this rank (Keras splits the batch across replicas [TF-2.6])."""
+        if self.ctx.world == 1:
+            return x, y
+        n = len(x) // self.ctx.world
+        sl = slice(self.ctx.rank * n, (self.ctx.rank + 1) * n)
+        return x[sl], (None if y is None else y[sl])
+
+    # ---- checkpoints (engine.py:55-78, 103-106, 224-231) -----------------------------------------------------
+    def get_ckpts(self, base_path):
+        regex_pattern = fr'^{self.ckpt_pattern}\.index$'.format(epoch=r'(\d+)')
+        files = [f for f in os.listdir(base_path) if re.match(regex_pattern, f)]
+        steps = [int(re.sub(regex_pattern, r'\1', f)) for f in files]
+        paths = [os.path.join(base_path, f[:-len('.index')]) for f in files]
+        return OrderedDict(sorted(zip(steps, paths), key=lambda x: x[0]))
+
+    def _auto_resume(self, base_path):
+        if not os.path.exists(base_path):
+            return
+        ckpts = self.get_ckpts(base_path)
+        if not ckpts:
+            return
+        latest_step = max(ckpts.keys())
+        self.load(ckpts[latest_step])
+        self.current_step = latest_step
+        logging.warning(f'Resumed from {latest_step}')
+
+    def save(self, path, fileformat=None):
+        """Weights + Adam slots + BN moving statistics + step counters: `<path>.index` (JSON) and `<path>.data-00000-of-00001`."""
+        dm = self.device_model
+        if self.ctx.world > 1:
+            dm.comm_average_state()      # BN moving statistics: mean over replicas (ON_READ / MEAN aggregation [TF-2.6])
+        if self.ctx.rank != 0:
+            return self
+        m, v, iterations = dm.get_opt_state()
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        with open(path + '.data-00000-of-00001', 'wb') as f:
+            np.savez(f, params=dm.get_params(), state=dm.get_state(), adam_m=m, adam_v=v)
+        index = dict(format='dnnca-ckpt-1', step=int(self.current_step), iterations=int(iterations),
+                     learning_rate=float(self.learning_rate),
+                     variables=[dict(name=n, shape=list(s), trainable=t, offset=o) for n, s, t, o in dm.param_infos()])
+        with open(path + '.index', 'w') as f:      # written last: its presence marks a complete checkpoint
+            json.dump(index, f)
+        return self
+
+    def load(self, path):
+        dm = self.device_model
+        with open(path + '.index') as f:
+            index = json.load(f)
+        have = [(v['name'], tuple(v['shape']), v['trainable'], v['offset']) for v in index['variables']]
+        if have != [(n, tuple(s), t, o) for n, s, t, o in dm.param_infos()]:
+            raise ValueError(f'checkpoint {path} does not match the model (assert_existing_objects_matched)')
+        with np.load(path + '.data-00000-of-00001') as z:
+            dm.set_params(z['params'])
+            if dm.n_state:
+                dm.set_state(z['state'])
+            dm.set_opt_state(z['adam_m'], z['adam_v'], index['iterations'])
+        return self
+
+    # ---- training (engine.py:80-137) -------------------------------------------------------------------------
+    def train(self, dataset, val_data=None, save_path=None, save_freq=100, max_steps=None, early_stop_steps=None,
+              visualization=None, auto_resume=True, profile=False):
+        self._build(dataset)
+        dm = self.device_model
+        if auto_resume and save_path is not None:
+            self._auto_resume(os.path.join(save_path, 'checkpoints'))
+        schedule = eval(self.learning_rate_scheduler) if self.learning_rate_scheduler is not None else None  # engine.py:98-100
+        log_file = None
+        if save_path is not None and self.ctx.rank == 0:
+            os.makedirs(os.path.join(save_path, 'checkpoints'), exist_ok=True)
+            os.makedirs(os.path.join(save_path, 'tfevents'), exist_ok=True)
+            log_file = open(os.path.join(save_path, 'tfevents', 'train_log.csv'), 'a')
+        if visualization:
+            logging.warning('visualization callbacks are outside the accelerated path: ignored')
+        cfg = dm.loss_cfg(**self.loss.device_cfg())
+        results = History(self.model)
+        results.params = dict(epochs=max_steps, steps=1, verbose=0)
+        best_val, wait = np.inf, 0
+        it = iter(dataset)
+        step = self.current_step
+        if profile:
+            dm.profile_enable(1)
+        t0 = time.time()
+        while max_steps is None or step < max_steps:
+            try:
+                x, y = next(it)
+            except StopIteration:
+                logging.warning('dataset exhausted at step %d', step)
+                break
+            x, y = self._shard(np.asarray(x), np.asarray(y))
+            if schedule is not None:
+                self.learning_rate = float(schedule(step, self.learning_rate))
+            out = dm.train_step(x, y, self.learning_rate, cfg)
+            step += 1
+            self.current_step = step
+            logs = dict(loss=float(out.loss), lr=self.learning_rate)
+            if save_path is not None and step % save_freq == 0:
+                self.save(os.path.join(save_path, 'checkpoints', self.ckpt_pattern.format(epoch=step)))
+            if val_data is not None and step % save_freq == 0:
+                val = self._evaluate(val_data)
+                logs.update({'val_' + k: v for k, v in val.items()})
+                if early_stop_steps is not None:
+                    if val['loss'] < best_val:
+                        best_val, wait = val['loss'], 0
+                    else:
+                        wait += 1
+                        if wait >= early_stop_steps:
+                            results.log(step - 1, logs)
+                            logging.warning('early stopping at step %d', step)
+                            break
+            results.log(step - 1, logs)
+            if log_file is not None:
+                log_file.write('%d,%s\n' % (step, ','.join('%s=%.8g' % kv for kv in logs.items())))
+            if self.ctx.rank == 0 and (step % 100 == 0 or step == max_steps):
+                logging.info('step %d loss %.6f lr %.3g (%.1f steps/s)', step, out.loss, self.learning_rate,
+                             (step - results.epoch[0]) / max(time.time() - t0, 1e-9))
+        if log_file is not None:
+            log_file.close()
+        if profile and save_path is not None and self.ctx.rank == 0:
+            with open(os.path.join(save_path, 'tfevents', 'kernel_profile.txt'), 'w') as f:
+                for row in sorted(dm.profile(), key=lambda r: -r[2]):
+                    f.write('%-28s launches %8d  total %10.3f ms\n' % row[:3])
+        return results
+
+    # ---- evaluation (engine.py:139-210) ----------------------------------------------------------------------
+    def _evaluate(self, dataset):
+        """keras Model.evaluate(return_dict=True): mean loss over batches + pixel metrics, training=False."""
+        dm = self.device_model
+        cfg = dm.loss_cfg(**self.loss.device_cfg())
+        for m in self.metrics:
+            m.reset_state()
+        total, count = 0.0, 0
+        for x, y in dataset:
+            x, y = self._shard(np.asarray(x), np.asarray(y))
+            if len(x) == 0:
+                continue
+            for i in range(0, len(x), dm.max_batch):
+                xb, yb = x[i:i + dm.max_batch], y[i:i + dm.max_batch]
+                out = dm.eval_step(xb, yb, cfg)
+                total += float(out.loss) * len(xb)
+                count += len(xb)
+                for m in self.metrics:
+                    m.update_state(dm, yb)
+        if self.ctx.world > 1:
+            total, count = (float(v) for v in dm.comm_allreduce([total, count]))
+            for m in self.metrics:
+                m.merge(lambda c: dm.comm_allreduce(c.ravel()).reshape(c.shape).astype(np.float64))
+        results = OrderedDict(loss=total / max(count, 1))
+        for m in self.metrics:
+            r = m.result()
+            results[m.name] = float(r) if np.ndim(r) == 0 else [float(v) for v in r]
+        return results
+
+    def eval(self, dataset, save_path, viz_ds=None, tag='val', avoid_overwrite=False, export_path=None, export_images=False,
+             visualize_sensitivity=False, export_csv=False, min_interval=1, step_range=None, overlay=False,
+             export_casewise_metrics=False):
+        self._build(dataset)
+        ckpt_path = os.path.join(save_path, 'checkpoints')
+        if not export_path:
+            export_path = os.path.join(save_path, 'tfevents')
+        if os.path.exists(os.path.join(export_path, tag)):
+            if avoid_overwrite:
+                while os.path.exists(os.path.join(export_path, tag)):
+                    tag += '_'
+            else:
+                raise ValueError(f'tag: {tag} already exists.')
+        if step_range is None:
+            step_range = 0, float('inf')
+        else:
+            assert len(step_range) == 2
+            assert 0 <= step_range[0] <= step_range[1]
+        if viz_ds is not None or export_images or visualize_sensitivity or overlay:
+            logging.warning('visualisation / image export are outside the accelerated path: ignored')
+        rows = OrderedDict()
+        previous_step = None
+        for ckpt_step, ckpt_path_ in self.get_ckpts(ckpt_path).items():
+            if not step_range[0] <= ckpt_step <= step_range[1]:
+                continue
+            if previous_step is not None and (ckpt_step - previous_step) < min_interval:
+                logging.warning(f'Ignored {ckpt_path_} due to min_interval:{min_interval}.')
+                continue
+            previous_step = ckpt_step
+            self.load(ckpt_path_)
+            rows[ckpt_step] = self._evaluate(dataset)
+        if export_csv and self.ctx.rank == 0:
+            os.makedirs(os.path.join(export_path, tag), exist_ok=True)
+            with open(os.path.join(export_path, tag, 'results.csv'), 'w') as f:
+                cols = list(next(iter(rows.values())).keys()) if rows else ['loss']
+                f.write('step,' + ','.join(cols) + '\n')
+                for step, r in rows.items():
+                    f.write(str(step) + ',' + ','.join(str(r[c]) for c in cols) + '\n')
+        return rows
+
+    def predict(self, dataset):
+        """Probabilities [N, H, W, 1] for every element of `dataset` (elements are x or (x, ...))."""
+        self._build(dataset)
+        dm = self.device_model
+        outs = []
+        for el in dataset:
+            x = np.asarray(el[0] if isinstance(el, (tuple, list)) else el)
+            for i in range(0, len(x), dm.max_batch):
+                outs.append(dm.forward(x[i:i + dm.max_batch], training=False))
+        return np.concatenate(outs) if outs else np.zeros((0,))
+
+    def get_config(self):
+        return self.model_config

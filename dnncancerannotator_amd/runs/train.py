@@ -1,0 +1,44 @@
+"""`annotator train` -- annotator/runs/train.py:21-94: dump the options, build datasets, train, dump the results."""
+
+import os
+
+from .. import data, dump, engine, load
+
+
+def make_dataset(paths, options, training):
+    """Dataset for `--data_path`.  Supported sources: `synthetic[:HxW[xC]]` (seeded synthetic slices) and `.npz` files
+    holding `x` [N,H,W,C] in [0,1] and `y` [N,H,W].  The reference's image-folder / TFRecord pipeline (data.py:157-207)
+    with its augmentations runs on TensorFlow and is outside the accelerated hot path."""
+    batch_size = options.get('batch_size', 8)
+    first = paths[0]
+    if first.startswith('synthetic'):
+        dims = [int(v) for v in first.split(':')[1].split('x')] if ':' in first else []
+        h, w = (dims + [512, 512])[:2] if len(dims) >= 2 else (512, 512)
+        c = dims[2] if len(dims) > 2 else 1
+        return data.SyntheticDataset(batch_size, h, w, c, repeat=training, n_batches=4 if training else 2)
+    if all(p.endswith('.npz') for p in paths):
+        import numpy as np
+        xs, ys = zip(*((z['x'], z['y']) for z in map(np.load, paths)))
+        return data.ArrayDataset(np.concatenate(xs), np.concatenate(ys), batch_size, repeat=training, drop_remainder=training)
+    raise NotImplementedError('data_path %r: supported sources are synthetic[:HxW[xC]] and .npz files' % (paths,))
+
+
+def train(config, save_path, data_path, max_steps, early_stop_steps=None, save_freq=500, validate=False,
+          val_data_path=None, visualize=False, profile=False):
+    config = load.load_config(config)
+    dump.dump_options(os.path.join(save_path, 'options.yaml'), avoid_overwrite=True, config=config, save_path=save_path,
+                      data_path=data_path)
+    options = config.get('data_options', {})
+    ds = make_dataset(data_path, options.get('train', {}), training=True)
+    if validate:
+        assert val_data_path is not None
+        val_ds = make_dataset(val_data_path, options.get('eval', {}), training=False)
+    else:
+        val_ds = None
+    model = engine.TFKerasModel(config)
+    results = model.train(ds, save_path=os.path.join(save_path), max_steps=max_steps, early_stop_steps=early_stop_steps,
+                          save_freq=save_freq, val_data=val_ds, visualization={} if not visualize else {'train': None},
+                          profile=profile)
+    if model.ctx.rank == 0:
+        dump.dump_train_results(os.path.join(save_path, 'results.pkl'), results, format_='pickle')
+    return results

@@ -136,6 +136,7 @@ int dnnca_pixel_confusion(void* model, const float* y_hw, int batch, const float
 int dnnca_comm_unique_id(void* id_out /* DNNCA_UNIQUE_ID_BYTES */);
 int dnnca_comm_init(void* model, int rank, int world, const void* unique_id, size_t id_len);   /* world == 1: no-op */
 int dnnca_comm_world(void* model, int* rank, int* world);
+int dnnca_comm_broadcast_weights(void* model, int root);   /* weights, BN statistics and Adam slots of `root` on every rank */
 int dnnca_comm_average_state(void* model);          /* BN moving statistics: mean over ranks before a checkpoint */
 int dnnca_comm_allreduce_host(void* model, float* values, int n, int op /* 0 sum, 1 max */);
 

@@ -1,0 +1,149 @@
+"""-m gpu: the engine facade end to end (train / checkpoints / resume / evaluate / predict) and full-size properties."""
+
+import os
+
+import numpy as np
+import pytest
+
+import helpers as Hp
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+UNET = dict(n_filters_first=3, n_downsample=3, rate=2, kernel_size=3, conv_stride=1, bn=False, padding='same')
+CONFIG = {
+    'model': 'UNetAnnotator', 'model_options': UNET,
+    'deploy_options': {'optimizer': 'adam', 'LearningRateScheduler': 'lambda epoch, current_lr: 0.001 * 0.96 ** (epoch // 1000)',
+                       'loss': {'class_name': 'WeightedCrossentropy', 'config': {'weight_mul': 3.0}}, 'enable_multigpu': False,
+                       'metrics': [{'Precision': {'thresholds': 0.8, 'name': 'pixel/precision'}},
+                                   {'FBetaScore': {'thresholds': 0.5, 'beta': 1.0, 'name': 'pixel/F1-score'}},
+                                   {'AUC': {'curve': 'ROC', 'name': 'pixel/AUROC', 'num_thresholds': 50}}]},
+}
+
+
+def test_engine_train_checkpoint_resume_eval(gpu, tmp_path):
+    from dnncancerannotator_amd import data, engine
+    save = str(tmp_path / 'run')
+    ds = data.SyntheticDataset(4, 64, 64, 1, n_batches=2, seed=3)
+    m = engine.TFKerasModel(CONFIG)
+    res = m.train(ds, save_path=save, max_steps=30, save_freq=10, val_data=data.SyntheticDataset(4, 64, 64, 1, n_batches=1, seed=9, repeat=False))
+    assert res.epoch == list(range(30)) and len(res.history['loss']) == 30
+    assert res.history['loss'][-1] < res.history['loss'][0]                 # it learns the synthetic discs
+    assert list(m.get_ckpts(os.path.join(save, 'checkpoints')).keys()) == [10, 20, 30]
+    assert 'val_loss' in res.history and len(res.history['val_loss']) == 3  # validation every save_freq steps
+    w30 = m.device_model.get_params()
+
+    # auto-resume: a fresh engine continues from ckpt-30 with the Adam slots and the step counter
+    m2 = engine.TFKerasModel(CONFIG)
+    res2 = m2.train(ds, save_path=save, max_steps=32, save_freq=10)
+    assert res2.epoch == [30, 31] and m2.current_step == 32
+    m3 = engine.TFKerasModel(CONFIG)
+    m3._build(ds)
+    m3.load(os.path.join(save, 'checkpoints', 'ckpt-30'))
+    assert np.array_equal(m3.device_model.get_params(), w30)
+    assert m3.device_model.get_opt_state()[2] == 30
+
+    # evaluate every checkpoint in a step range, with pixel metrics computed from device-side confusion counts
+    ev = data.SyntheticDataset(4, 64, 64, 1, n_batches=2, seed=11, repeat=False)
+    rows = m3.eval(ev, save_path=save, tag='val', export_csv=True, step_range=(10, 20))
+    assert list(rows.keys()) == [10, 20]
+    assert set(rows[10]) == {'loss', 'pixel/precision', 'pixel/F1-score', 'pixel/AUROC'}
+    assert os.path.exists(os.path.join(save, 'tfevents', 'val', 'results.csv'))
+    with pytest.raises(ValueError):
+        m3.eval(ev, save_path=save, tag='val')                              # tag already exists (engine.py:160-163)
+
+    # predict == oracle forward with the trained weights
+    x, _ = next(iter(ev))
+    prob = m3.predict([(x,)])
+    spec = O.ModelSpec('unet', 1, **UNET)
+    params = O.unflatten(spec, m3.device_model.get_params())
+    pref, _ = O.predict(spec, params, x)
+    assert np.abs(prob - pref).max() < 1e-4
+
+
+def test_label_assertion_and_batch_errors(gpu):
+    m = gpu.DeviceModel('unet', 1, 32, 32, 2, **UNET)
+    x = np.zeros((2, 32, 32, 1), np.float32)
+    y = np.full((2, 32, 32), 1.5, np.float32)
+    with pytest.raises(Exception) as e:                                     # assert_on_max (utils/losses.py:91)
+        m.train_step(x, y, 1e-3, m.loss_cfg(weight_mul=3.0))
+    assert 'label outside' in str(e.value)
+    with pytest.raises(ValueError):
+        m.forward(np.zeros((3, 32, 32, 1), np.float32))                     # more than max_batch
+    with pytest.raises(ValueError):
+        m.forward(np.zeros((2, 16, 16, 1), np.float32))                     # not the built input shape
+    out = m.train_step(x, np.zeros((2, 32, 32), np.float32), 1e-3, m.loss_cfg(weight_mul=3.0))
+    assert out.positive_rate == 0.0 and out.weight == 3.0                   # no positives: weight = mul * 1 + add
+    m.close()
+    with pytest.raises(Exception):
+        gpu.DeviceModel('unet', 1, 30, 30, 2, **UNET)                       # 30 not divisible by 2^3
+    with pytest.raises(Exception):
+        gpu.DeviceModel('unet', 1, 32, 32, 2, **dict(UNET, padding='valid'))
+
+
+def test_full_size_tuned_vs_generic_and_directional_derivative(gpu):
+    """BASELINE size (8 x 512 x 512 x 1): the tuned MFMA path against the generic kernels, and the analytic gradient
+    against a central finite difference of the loss along a random direction (size-independent property)."""
+    from dnncancerannotator_amd.synthetic import synthetic_batch
+    B, H, W = 8, 512, 512
+    x, y = synthetic_batch(B, H, W, 1)
+    tuned = gpu.DeviceModel('unet', 1, H, W, B, **UNET)
+    generic = gpu.DeviceModel('unet', 1, H, W, B, force_generic=True, **UNET)
+    tuned.init_glorot(seed=2)
+    p0 = tuned.get_params()
+    rng = np.random.default_rng(7)
+    p0 = (p0 + rng.uniform(-0.05, 0.05, p0.shape)).astype(np.float32)      # non-zero biases
+    tuned.set_params(p0)
+    generic.set_params(p0)
+    cfg = tuned.loss_cfg(weight_mul=3.0)
+    pt, lt = tuned.forward(x, training=False, return_logits=True)
+    pg, lg = generic.forward(x, training=False, return_logits=True)
+    tol = 2e-4 * max(1.0, float(np.abs(lg).max()))
+    assert np.abs(lt - lg).max() <= tol
+    for thr in (0.5, 0.8):                                                  # Keras convention: prob > threshold
+        decided = np.abs(lg - np.log(thr / (1 - thr))) > tol
+        mt, mg = (pt > thr), (pg > thr)
+        assert np.array_equal(mt[decided], mg[decided])
+        inter = np.logical_and(mt, mg).sum()
+        dice = 2.0 * inter / max(mt.sum() + mg.sum(), 1)
+        assert dice > 0.9999 or mt.sum() + mg.sum() == 0
+    ot = tuned.train_step(x, y, 0.0, cfg)                                   # lr 0: gradients without moving the weights
+    og = generic.train_step(x, y, 0.0, cfg)
+    assert abs(ot.loss - og.loss) <= 1e-5 * max(1.0, abs(og.loss))
+    gt, gg = tuned.get_grads(), generic.get_grads()
+    assert Hp.rel_err(gt, gg) <= 2e-3
+    # directional derivative: (L(w + e d) - L(w - e d)) / 2e  ==  g . d
+    d = rng.standard_normal(p0.shape).astype(np.float32)
+    d /= np.linalg.norm(d)
+    eps = 2e-3
+    tuned.set_params(p0 + eps * d)
+    lp = tuned.eval_step(x, y, cfg).loss
+    tuned.set_params(p0 - eps * d)
+    lm = tuned.eval_step(x, y, cfg).loss
+    fd = (lp - lm) / (2 * eps)
+    an = float(np.dot(gt.astype(np.float64), d.astype(np.float64)))
+    assert abs(fd - an) <= 0.05 * max(abs(an), 1e-3), (fd, an)
+    tuned.close()
+    generic.close()
+
+
+@pytest.mark.parametrize('arch, C, opts, B, size', [
+    ('unet', 1, dict(n_filters_first=64, n_downsample=4, bn=True), 1, 64),        # configs/unet_big.yaml
+    ('mulmo', 3, dict(n_filters_first=16, n_downsample=4, bn=True), 2, 64),       # configs/mulmo_unet.yaml
+])
+def test_reference_configs_against_oracle(gpu, arch, C, opts, B, size):
+    """The real unet_big / mulmo_unet hyper-parameters (generic kernels) against the float32 oracle on one small batch."""
+    full = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', **opts)
+    spec = O.ModelSpec(arch, C, **full)
+    params = O.init_params(spec, seed=2)
+    x, y = O.synthetic_batch(B, size, size, C)
+    m = gpu.DeviceModel(arch, C, size, size, B, **full)
+    m.set_params(O.flatten(spec, params))
+    cfg = dict(weight_mul=3.0)
+    out = m.train_step(x, y, 1e-3, m.loss_cfg(**cfg))
+    p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    loss, grads, _, state = O.loss_and_grads(spec, p64, x.astype(np.float64), y, cfg, training=True)
+    assert abs(out.loss - loss) <= 2e-4 * max(1.0, abs(loss))
+    assert Hp.rel_err(m.get_grads(), O.flatten(spec, grads)) <= 5e-3
+    assert np.abs(m.get_state() - O.flatten(spec, dict(p64, **state), trainable=False)).max() <= 1e-4
+    m.close()
