@@ -67,9 +67,6 @@ class TFKerasModel:
         self.enable_multigpu = deploy.pop('enable_multigpu', True)
         if not self.enable_multigpu and self.ctx.world > 1:
             raise ValueError('enable_multigpu is false but WORLD_SIZE is %d' % self.ctx.world)
-        if self.enable_multigpu and self.ctx.world == 1 and device.device_count() > 1 and self.ctx.rank == 0:
-            logging.warning('enable_multigpu: %d GPUs visible but one process; launch with '
-                            '`python -m dnncancerannotator_amd.launch --nproc N ...` for data parallel', device.device_count())
         self.learning_rate_scheduler = deploy.pop('LearningRateScheduler', None)
         model = getattr(models, model_config['model'])(**model_config['model_options'])
         self.loss = custom_losses.get(deploy['loss']) if 'loss' in deploy else custom_losses.WeightedCrossentropy()
@@ -90,6 +87,9 @@ class TFKerasModel:
         if global_batch % self.ctx.world:
             raise ValueError('global batch %d is not divisible by %d ranks' % (global_batch, self.ctx.world))
         device.init_device(self.ctx.local_rank)
+        if self.enable_multigpu and self.ctx.world == 1 and device.device_count() > 1:
+            logging.warning('enable_multigpu: %d GPUs visible but one process; launch with '
+                            '`python -m dnncancerannotator_amd.launch --nproc N ...` for data parallel', device.device_count())
         self.device_model = self.model.build([global_batch // self.ctx.world] + list(shape[1:]), seed=0)
         self.device_model.set_adam(**self.adam)
         if self.ctx.world > 1:
