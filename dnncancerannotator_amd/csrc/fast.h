@@ -7,7 +7,8 @@ namespace dnnca {
 
 int fast_prepare(Model* m);     // per-step operand preparation (weights -> MFMA B operands)
 int fast_finish_backward(Model* m);   // folds the weight-gradient slabs into the flat gradient vector
-void fast_release(Model* m);    // drop the per-model plan
+void fast_release(Model* m);
+unsigned long long* fast_debug_stamps(Model* m);   // tuning aid: in-kernel s_memtime stamps (DNNCA_STAMPS)    // drop the per-model plan
 bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 bool fast_pool_fwd(Model* m, int B, Op& o, double bytes);

@@ -19,6 +19,7 @@
 // cores work on the current one (one LDS buffer, several blocks per CU).
 // exact fp32: the f32 MFMA is a chain of fmaf (MI355X guide, "FP32-input MFMA"), so parity with the oracle holds to
 // fp32 rounding.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "fast.h"
@@ -42,32 +43,54 @@ struct TG {
     static constexpr int npf(int nt) { return (N4 + nt - 1) / nt; }   // prefetch registers (float4) per thread
 };
 
-// issue the global loads of one (TH+2)-row halo tile into registers; zero outside the image
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue (s_waitcnt
+// vmcnt(0)), which would make every tile wait for its epilogue stores and for the prefetch loads of the next tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Staging of one (TH+2)-row halo tile.  The (row, 16-byte column) a thread fetches for prefetch register k depends only
+// on its thread id, so it is computed once per kernel (TileMap); per tile only the tile origin changes.
 template <int C, int TW, int NT>
-__device__ __forceinline__ void tile_issue(float4* pre, const float* __restrict__ src, int b, int x0, int y0, int H, int W,
-                                           int tid) {
+struct TileMap {
+    using T = TG<C, TW>;
+    static constexpr int NPF = T::npf(NT);
+    int row[NPF], c4[NPF];
+    __device__ __forceinline__ void init(int tid) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int idx = tid + k * NT;
+            row[k] = idx < T::N4 ? idx / T::LS4 : -100000;    // out-of-tile slots never pass the row test
+            c4[k] = idx - (idx / T::LS4) * T::LS4;
+        }
+    }
+};
+
+// Issue the global loads of one tile into registers.  The loads are unconditional (addresses clamped into the image)
+// so the issue phase is branch-free; what lies outside the image is zeroed at commit time from the returned bit mask.
+template <int C, int TW, int NT>
+__device__ __forceinline__ unsigned tile_issue(float4* pre, const TileMap<C, TW, NT>& mp, const float* __restrict__ src,
+                                               int b, int x0, int y0, int H, int W) {
     using T = TG<C, TW>;
     const int rowlen4 = W * C / 4;
     const int g40 = (x0 * C - T::HL) / 4;
-    const float4* base = reinterpret_cast<const float4*>(src + (size_t)b * H * W * C);
+    const float4* base = reinterpret_cast<const float4*>(src) + (size_t)b * H * rowlen4;
+    unsigned ok = 0;
 #pragma unroll
     for (int k = 0; k < T::npf(NT); ++k) {
-        const int idx = tid + k * NT;
-        const int row = idx / T::LS4, c4 = idx - row * T::LS4;
-        const int iy = y0 - 1 + row, g4 = g40 + c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < T::N4 && iy >= 0 && iy < H && g4 >= 0 && g4 < rowlen4) v = base[(size_t)iy * rowlen4 + g4];
-        pre[k] = v;
+        const int iy = y0 - 1 + mp.row[k], g4 = g40 + mp.c4[k];
+        ok |= ((unsigned)iy < (unsigned)H && (unsigned)g4 < (unsigned)rowlen4) ? (1u << k) : 0u;
+        const int iyc = min(max(iy, 0), H - 1), g4c = min(max(g4, 0), rowlen4 - 1);
+        pre[k] = base[(size_t)iyc * rowlen4 + g4c];
     }
+    return ok;
 }
 
 template <int C, int TW, int NT>
-__device__ __forceinline__ void tile_commit(const float4* pre, float4* lds4, int tid) {
+__device__ __forceinline__ void tile_commit(const float4* pre, unsigned ok, float4* lds4, int tid) {
     using T = TG<C, TW>;
 #pragma unroll
     for (int k = 0; k < T::npf(NT); ++k) {
         const int idx = tid + k * NT;
-        if (idx < T::N4) lds4[idx] = pre[k];
+        if (idx < T::N4) lds4[idx] = (ok >> k) & 1u ? pre[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -96,7 +119,22 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
     const int co = n % CO;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
 
+    // B operand (one register per K-step) and bias first; drain them and hide their origin from the compiler:
+    // otherwise hipcc keeps `s_waitcnt vmcnt(..0)` for these registers inside the tile loop, and since vmcnt retires in
+    // order that wait also drains the tile prefetch issued just before the MFMAs (load latency serialised per tile).
+    float breg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) breg[s] = p.bmat[s * 64 + lane];
+    float bias = n < N ? p.bias[co] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(breg[s]));
+    asm volatile("" : "+v"(bias));
+
     float4 pre[NSRC][T::npf(NT)];
+    TileMap<C, TW, NT> mp;
+    mp.init(tid);
+    unsigned okm = 0;          // in-image mask of the prefetched tile (the same for every source)
     int tile = blockIdx.x;
     auto decode = [&](int t, int& b, int& x0, int& y0) {
         const int bx = t % p.tiles_x, by = (t / p.tiles_x) % p.tiles_y;
@@ -108,26 +146,22 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_issue<C, TW, NT>(pre[s], p.src[s], b, x0, y0, p.H, p.W, tid);
+        for (int s = 0; s < NSRC; ++s) okm = tile_issue<C, TW, NT>(pre[s], mp, p.src[s], b, x0, y0, p.H, p.W);
     }
-    float breg[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) breg[s] = p.bmat[s * 64 + lane];
-    const float bias = n < N ? p.bias[co] : 0.f;
 
 #pragma unroll 1
     while (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(pre[s], lds4 + s * T::N4, tid);
-        __syncthreads();
+        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(pre[s], okm, lds4 + s * T::N4, tid);
+        lds_barrier();
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
             decode(next, nb, nx0, ny0);
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) tile_issue<C, TW, NT>(pre[s], p.src[s], nb, nx0, ny0, p.H, p.W, tid);
+            for (int s = 0; s < NSRC; ++s) okm = tile_issue<C, TW, NT>(pre[s], mp, p.src[s], nb, nx0, ny0, p.H, p.W);
         }
         // every wave owns NCH = 4 M-tiles (same column block tx, rows ty0 + 2i) and interleaves their MFMA chains:
         // independent accumulators keep the matrix pipe issuing back to back (a dependent 16x16x4 f32 chain stalls
@@ -172,10 +206,20 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();
+        lds_barrier();
         tile = next;
     }
 }
+
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP(i)                                                                                        \
+    do {                                                                                                \
+        if (p.stamps && wave == 0 && lane == 0 && it < 4) p.stamps[((size_t)blockIdx.x * 4 + it) * 8 + (i)] = stamp(); \
+    } while (0)
 
 // ================================================================================================ backward (fused)
 struct BwdArgs {
@@ -190,6 +234,7 @@ struct BwdArgs {
     int tiles_x, tiles_y;
     float alpha;             // slope of the masked activation
     int dbg;                 // tuning aid (DNNCA_DBG): bit 0 skip the data-gradient phase, bit 1 skip the weight-gradient phase
+    unsigned long long* stamps;   // tuning aid (DNNCA_STAMPS): [block][tile slot 0..3][8] s_memtime stamps of wave 0
 };
 
 template <int C, int NSRC, int CO>
@@ -221,7 +266,7 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     constexpr int TW = Wc::TW, Gw = Wc::Gw, Gd = Wc::Gd, COd = Wc::COd, NPASS = Wc::NPASS, SRd = Wc::SRd, KSd = Wc::KSd;
     constexpr int MT = Wc::MT, WRw = Wc::WRw, LSg = TGg::LS, LSx = TGx::LS, Nw = Gw * CO, Nd = Gd * COd;
     static_assert(TW % (16 * Gd) == 0, "tile width must hold whole dgrad M-tiles");
-    __shared__ float4 lds4[Wc::LDS4 + NW * 48];        // staged tiles (reused for the final reduction) + output rows
+    __shared__ float4 lds4[Wc::LDS4 + NW * 48 + 1];    // staged tiles (reused for the final reduction) + output rows + constants
     float* gl = reinterpret_cast<float*>(lds4);
     float* xl = reinterpret_cast<float*>(lds4 + TGg::N4);
     float* orow = reinterpret_cast<float*>(lds4 + Wc::LDS4) + (threadIdx.x >> 6) * 192;
@@ -230,18 +275,25 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     const int m16 = lane & 15, q = lane >> 4, n = m16;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
 
-    // wgrad A-operand addressing: row mrow = (dy, j) of the group's window; last valid row is the all-ones bias row
-    int offA[MT], kind[MT];
+    // two constants in LDS (1.0 for the all-ones bias row of the weight-gradient A operand, 0.0 for padding rows and
+    // padding columns): the MFMA operands are then plain LDS reads, no per-MFMA select
+    float* cst = reinterpret_cast<float*>(lds4 + Wc::LDS4 + NW * 48);
+    if (threadIdx.x == 0) { cst[0] = 1.0f; cst[1] = 0.0f; }
+    const int CST1 = (int)(cst - xl), CST0 = CST1 + 1;     // float offsets relative to xl (x tiles) ...
+    const int GCST0 = (int)(cst + 1 - gl);                 // ... and to gl (dz tile)
+    // wgrad A-operand addressing: row mrow = (dy, j) of the group's window; last valid row is the all-ones bias row.
+    // stepA[t] is what one K-step (4 groups) adds to the address: 0 for the constant rows
+    int offA[MT], stepA[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int mrow = 16 * t + m16;
         if (mrow < 3 * WRw) {
             const int dy = mrow / WRw, j = mrow - dy * WRw;
             offA[t] = dy * LSx + TGx::LEAD + j + q * (Gw * C);
-            kind[t] = 0;
+            stepA[t] = 4 * Gw * C;
         } else {
-            offA[t] = 0;
-            kind[t] = mrow == 3 * WRw ? 1 : 2;
+            offA[t] = mrow == 3 * WRw ? CST1 : CST0;
+            stepA[t] = 0;
         }
     }
     f32x4 acc[NSRC][MT];
@@ -254,12 +306,21 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     if (DGRAD) {
 #pragma unroll
         for (int s = 0; s < NPASS * KSd; ++s) breg[s] = p.bmat[s * 64 + lane];
+        // drain + hide the origin of these registers (see k_pgfwd): no vmcnt waits for them inside the tile loop
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NPASS * KSd; ++s) asm volatile("" : "+v"(breg[s]));
     }
     // dgrad epilogue: column n = (dxp, co) of pass ps -> (source, channel)
     const int dxp = n / COd, cod = n % COd;
 
     float4 preg[TGg::npf(NT)];
     float4 prex[NSRC][TGx::npf(NT)];
+    TileMap<CO, TW, NT> mpg;
+    TileMap<C, TW, NT> mpx;
+    mpg.init(tid);
+    mpx.init(tid);
+    unsigned okg = 0, okx = 0;
     auto decode = [&](int t, int& b, int& x0, int& y0) {
         const int bx = t % p.tiles_x, by = (t / p.tiles_x) % p.tiles_y;
         b = t / (p.tiles_x * p.tiles_y);
@@ -270,28 +331,32 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     if (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
-        tile_issue<CO, TW, NT>(preg, p.dz, b, x0, y0, p.H, p.W, tid);
+        okg = tile_issue<CO, TW, NT>(preg, mpg, p.dz, b, x0, y0, p.H, p.W);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_issue<C, TW, NT>(prex[s], p.x[s], b, x0, y0, p.H, p.W, tid);
+        for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], b, x0, y0, p.H, p.W);
     }
 
+    int it = 0;
 #pragma unroll 1
     while (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
-        tile_commit<CO, TW, NT>(preg, lds4, tid);
+        STAMP(0);
+        tile_commit<CO, TW, NT>(preg, okg, lds4, tid);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(prex[s], lds4 + TGg::N4 + s * TGx::N4, tid);
-        __syncthreads();
+        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(prex[s], okx, lds4 + TGg::N4 + s * TGx::N4, tid);
+        lds_barrier();
+        STAMP(1);
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
             decode(next, nb, nx0, ny0);
-            tile_issue<CO, TW, NT>(preg, p.dz, nb, nx0, ny0, p.H, p.W, tid);
+            okg = tile_issue<CO, TW, NT>(preg, mpg, p.dz, nb, nx0, ny0, p.H, p.W);
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) tile_issue<C, TW, NT>(prex[s], p.x[s], nb, nx0, ny0, p.H, p.W, tid);
+            for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], nb, nx0, ny0, p.H, p.W);
         }
 
+        STAMP(2);
         // ---- data gradient: conv of dz with the flipped kernel; M-tiles of 16 groups x Gd pixels
         if (DGRAD && !(p.dbg & 1)) {
             // M-tiles of this wave: t = wave + 4j, j < MTX*TH/4; NCH of them are processed with interleaved MFMA chains
@@ -359,25 +424,35 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
                 }
             }
         }
+        STAMP(3);
         // ---- weight gradient: K = pixel groups (4 per MFMA); every wave takes rows ty = wave, wave + 4
 #pragma unroll 1
         for (int ty = (p.dbg & 2) ? TH : wave; ty < TH; ty += NW) {
-            const float* gr = gl + (ty + 1) * LSg + TGg::HL + q * Nw + n;
+            const int goff = n < Nw ? (ty + 1) * LSg + TGg::HL + q * Nw + n : GCST0;
+            const int gstep = n < Nw ? 4 * Nw : 0;
+            int aoffs[NSRC][MT];
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    aoffs[s][t] = stepA[t] ? s * (TGx::N4 * 4) + ty * LSx + offA[t] : offA[t];
 #pragma unroll
             for (int st = 0; st < TW / (4 * Gw); ++st) {
-                const float bv = n < Nw ? gr[st * 4 * Nw] : 0.f;
+                const float bv = gl[goff + st * gstep];
 #pragma unroll
-                for (int s = 0; s < NSRC; ++s) {
-                    const float* xr = xl + s * (TGx::N4 * 4) + ty * LSx + st * 4 * Gw * C;
+                for (int s = 0; s < NSRC; ++s)
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
-                        const float av = kind[t] == 0 ? xr[offA[t]] : (kind[t] == 1 ? 1.0f : 0.0f);
-                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[s][t], 0, 0, 0);
+                        // tiles whose 16 rows are all window rows use a compile-time step (immediate LDS offsets)
+                        const int ao = 16 * (t + 1) <= 3 * WRw ? aoffs[s][t] + st * (4 * Gw * C) : aoffs[s][t] + st * stepA[t];
+                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xl[ao], bv, acc[s][t], 0, 0, 0);
                     }
-                }
             }
         }
-        __syncthreads();
+        STAMP(4);
+        lds_barrier();
+        STAMP(5);
+        ++it;
         tile = next;
     }
 
@@ -609,11 +684,13 @@ struct PgPlan {                      // per-model table built lazily on the firs
     int fold_chunks = 0;
     int nblocks_cap = 512;
     int nthreads = 512;
+    unsigned long long* stamps = nullptr;
 };
 
 static std::map<Model*, PgPlan> g_plans;
 
 void fast_release(Model* m) { g_plans.erase(m); }
+unsigned long long* fast_debug_stamps(Model* m) { return g_plans[m].stamps; }
 
 static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
 
@@ -787,6 +864,15 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     a.mask[0] = o.maskA; a.mask[1] = o.maskB;
     a.alpha = o.mask_alpha;
     if (const char* e = getenv("DNNCA_DBG")) a.dbg = atoi(e);
+    if (const char* e = getenv("DNNCA_STAMPS")) {      // e = "C,NS,CO" of the kernel to stamp
+        int sc = 0, sn = 0, so = 0;
+        if (sscanf(e, "%d,%d,%d", &sc, &sn, &so) == 3 && sc == C && sn == NS && so == CO) {
+            if (!pl.stamps) {
+                if (m->alloc((void**)&pl.stamps, 1024 * 4 * 8 * 8) != DNNCA_OK) return false;
+            }
+            a.stamps = pl.stamps;
+        }
+    }
     for (int s = 0; s < NS; ++s) {
         auto it = pl.wslot.find({&o, s});
         if (it == pl.wslot.end()) return false;

@@ -910,6 +910,16 @@ int dnnca_profile_get(void* model, int index, char* name, size_t name_cap, int64
     return DNNCA_OK;
 }
 
+// development aid (not part of include/dnnca.h): copy the first `n` 64-bit stamps of the tuned backward kernel
+int dnnca_debug_read_stamps(void* model, unsigned long long* out, int n) {
+    MODEL(model);
+    unsigned long long* s = fast_debug_stamps(M);
+    if (!s) { set_error("no stamps"); return DNNCA_ESTATE; }
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    HIP_TRY(hipMemcpy(out, s, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return DNNCA_OK;
+}
+
 // development aid (not part of include/dnnca.h): n back-to-back launches of a trivial kernel on the model's stream
 __global__ void k_noop(float* p) { if (p == nullptr) *p = 0.f; }
 int dnnca_debug_launch_cost(void* model, int n, int blocks, float* us_per_launch) {
