@@ -53,13 +53,14 @@ template <int C, int TW, int NT>
 struct TileMap {
     using T = TG<C, TW>;
     static constexpr int NPF = T::npf(NT);
-    int row[NPF], c4[NPF];
-    __device__ __forceinline__ void init(int tid) {
+    int row[NPF], c4[NPF], off[NPF];      // off = row * rowlen4 + c4: float4 offset from the tile's first staged float4
+    __device__ __forceinline__ void init(int tid, int rowlen4) {
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int idx = tid + k * NT;
             row[k] = idx < T::N4 ? idx / T::LS4 : -100000;    // out-of-tile slots never pass the row test
             c4[k] = idx - (idx / T::LS4) * T::LS4;
+            off[k] = idx < T::N4 ? row[k] * rowlen4 + c4[k] : 0;
         }
     }
 };
@@ -68,18 +69,19 @@ struct TileMap {
 // so the issue phase is branch-free; what lies outside the image is zeroed at commit time from the returned bit mask.
 template <int C, int TW, int NT>
 __device__ __forceinline__ unsigned tile_issue(float4* pre, const TileMap<C, TW, NT>& mp, const float* __restrict__ src,
-                                               int b, int x0, int y0, int H, int W) {
+                                               int b, int x0, int y0, int B, int H, int W) {
     using T = TG<C, TW>;
     const int rowlen4 = W * C / 4;
     const int g40 = (x0 * C - T::HL) / 4;
-    const float4* base = reinterpret_cast<const float4*>(src) + (size_t)b * H * rowlen4;
+    const int tbase = (b * H + y0 - 1) * rowlen4 + g40;          // float4 index of the tile's (row 0, column 0); uniform
+    const int last4 = B * H * rowlen4 - 1;
+    const float4* base = reinterpret_cast<const float4*>(src);
     unsigned ok = 0;
 #pragma unroll
     for (int k = 0; k < T::npf(NT); ++k) {
         const int iy = y0 - 1 + mp.row[k], g4 = g40 + mp.c4[k];
         ok |= ((unsigned)iy < (unsigned)H && (unsigned)g4 < (unsigned)rowlen4) ? (1u << k) : 0u;
-        const int iyc = min(max(iy, 0), H - 1), g4c = min(max(g4, 0), rowlen4 - 1);
-        pre[k] = base[(size_t)iyc * rowlen4 + g4c];
+        pre[k] = base[min(max(tbase + mp.off[k], 0), last4)];    // clamped: what is outside the image is masked at commit
     }
     return ok;
 }
@@ -105,14 +107,15 @@ struct FwdArgs {
     float alpha;             // activation slope (<0: none)
 };
 
-template <int C, int NSRC, int CO, int NT>
+template <int C, int NSRC, int CO, int NT, bool DB>
 __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
     constexpr int G = 12 / CO, TX = 2, TW = 16 * G * TX, N = G * CO, NW = NT / 64;
     using T = TG<C, TW>;
     constexpr int WR = (G + 2) * C, SR = (WR + 3) / 4, KS = NSRC * 3 * SR, LS = T::LS;
-    __shared__ float4 lds4[NSRC * T::N4 + NW * 48];    // staged tiles + one 16x12 output row per wave
-    float* lds = reinterpret_cast<float*>(lds4);
-    float* orow = reinterpret_cast<float*>(lds4 + NSRC * T::N4) + (threadIdx.x >> 6) * 192;
+    // DB: two stage buffers -> the next tile is committed while other waves still read the current one, one barrier per tile
+    constexpr int STAGE4 = NSRC * T::N4, NBUF = DB ? 2 : 1;
+    __shared__ float4 lds4[NBUF * STAGE4 + NW * 48];   // staged tiles + one 16x12 output row per wave
+    float* orow = reinterpret_cast<float*>(lds4 + NBUF * STAGE4) + (threadIdx.x >> 6) * 192;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4, n = m;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
 
     float4 pre[NSRC][T::npf(NT)];
     TileMap<C, TW, NT> mp;
-    mp.init(tid);
+    mp.init(tid, p.W * C / 4);
     unsigned okm = 0;          // in-image mask of the prefetched tile (the same for every source)
     int tile = blockIdx.x;
     auto decode = [&](int t, int& b, int& x0, int& y0) {
@@ -146,22 +149,31 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) okm = tile_issue<C, TW, NT>(pre[s], mp, p.src[s], b, x0, y0, p.H, p.W);
+        for (int s = 0; s < NSRC; ++s) okm = tile_issue<C, TW, NT>(pre[s], mp, p.src[s], b, x0, y0, p.B, p.H, p.W);
     }
 
+    int buf = 0;
+    if (DB && tile < ntiles) {
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(pre[s], okm, lds4 + s * T::N4, tid);
+        lds_barrier();
+    }
 #pragma unroll 1
     while (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
+        if (!DB) {
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(pre[s], okm, lds4 + s * T::N4, tid);
-        lds_barrier();
+            for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(pre[s], okm, lds4 + s * T::N4, tid);
+            lds_barrier();
+        }
+        const float* lds = reinterpret_cast<const float*>(lds4 + buf * STAGE4);
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
             decode(next, nb, nx0, ny0);
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) okm = tile_issue<C, TW, NT>(pre[s], mp, p.src[s], nb, nx0, ny0, p.H, p.W);
+            for (int s = 0; s < NSRC; ++s) okm = tile_issue<C, TW, NT>(pre[s], mp, p.src[s], nb, nx0, ny0, p.B, p.H, p.W);
         }
         // every wave owns NCH = 4 M-tiles (same column block tx, rows ty0 + 2i) and interleaves their MFMA chains:
         // independent accumulators keep the matrix pipe issuing back to back (a dependent 16x16x4 f32 chain stalls
@@ -205,6 +217,13 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+        }
+        if (DB) {
+            if (next < ntiles) {
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(pre[s], okm, lds4 + (buf ^ 1) * STAGE4 + s * T::N4, tid);
+            }
+            buf ^= 1;
         }
         lds_barrier();
         tile = next;
@@ -257,7 +276,7 @@ struct BW {
     static constexpr int LDS4 = STAGE4 > RED4 ? STAGE4 : RED4;
 };
 
-template <int C, int NSRC, int CO, bool DGRAD, int NT>
+template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB>
 __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     constexpr int NW = NT / 64;
     using Wc = BW<C, NSRC, CO>;
@@ -266,10 +285,11 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     constexpr int TW = Wc::TW, Gw = Wc::Gw, Gd = Wc::Gd, COd = Wc::COd, NPASS = Wc::NPASS, SRd = Wc::SRd, KSd = Wc::KSd;
     constexpr int MT = Wc::MT, WRw = Wc::WRw, LSg = TGg::LS, LSx = TGx::LS, Nw = Gw * CO, Nd = Gd * COd;
     static_assert(TW % (16 * Gd) == 0, "tile width must hold whole dgrad M-tiles");
-    __shared__ float4 lds4[Wc::LDS4 + NW * 48 + 1];    // staged tiles (reused for the final reduction) + output rows + constants
-    float* gl = reinterpret_cast<float*>(lds4);
-    float* xl = reinterpret_cast<float*>(lds4 + TGg::N4);
-    float* orow = reinterpret_cast<float*>(lds4 + Wc::LDS4) + (threadIdx.x >> 6) * 192;
+    // DB: two stage buffers -> the next tile is committed while other waves still read the current one, one barrier per tile
+    constexpr int STAGE4 = Wc::STAGE4, NBUF = DB ? 2 : 1;
+    constexpr int MAIN4 = NBUF * STAGE4 > Wc::RED4 ? NBUF * STAGE4 : Wc::RED4;
+    __shared__ float4 lds4[MAIN4 + NW * 48 + 1];       // staged tiles (reused for the final reduction) + output rows + constants
+    float* orow = reinterpret_cast<float*>(lds4 + MAIN4) + (threadIdx.x >> 6) * 192;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4, n = m16;
@@ -277,10 +297,10 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
 
     // two constants in LDS (1.0 for the all-ones bias row of the weight-gradient A operand, 0.0 for padding rows and
     // padding columns): the MFMA operands are then plain LDS reads, no per-MFMA select
-    float* cst = reinterpret_cast<float*>(lds4 + Wc::LDS4 + NW * 48);
+    float* cst = reinterpret_cast<float*>(lds4 + MAIN4 + NW * 48);
     if (threadIdx.x == 0) { cst[0] = 1.0f; cst[1] = 0.0f; }
-    const int CST1 = (int)(cst - xl), CST0 = CST1 + 1;     // float offsets relative to xl (x tiles) ...
-    const int GCST0 = (int)(cst + 1 - gl);                 // ... and to gl (dz tile)
+    const float* ldsf = reinterpret_cast<const float*>(lds4);
+    constexpr int CST1 = (MAIN4 + NW * 48) * 4, CST0 = CST1 + 1;     // absolute float indices of the constants
     // wgrad A-operand addressing: row mrow = (dy, j) of the group's window; last valid row is the all-ones bias row.
     // stepA[t] is what one K-step (4 groups) adds to the address: 0 for the constant rows
     int offA[MT], stepA[MT];
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
             offA[t] = dy * LSx + TGx::LEAD + j + q * (Gw * C);
             stepA[t] = 4 * Gw * C;
         } else {
-            offA[t] = mrow == 3 * WRw ? CST1 : CST0;
+            offA[t] = mrow == 3 * WRw ? CST1 : CST0;       // absolute index (window rows are relative to the x tile)
             stepA[t] = 0;
         }
     }
@@ -318,8 +338,8 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     float4 prex[NSRC][TGx::npf(NT)];
     TileMap<CO, TW, NT> mpg;
     TileMap<C, TW, NT> mpx;
-    mpg.init(tid);
-    mpx.init(tid);
+    mpg.init(tid, p.W * CO / 4);
+    mpx.init(tid, p.W * C / 4);
     unsigned okg = 0, okx = 0;
     auto decode = [&](int t, int& b, int& x0, int& y0) {
         const int bx = t % p.tiles_x, by = (t / p.tiles_x) % p.tiles_y;
@@ -331,29 +351,40 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     if (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
-        okg = tile_issue<CO, TW, NT>(preg, mpg, p.dz, b, x0, y0, p.H, p.W);
+        okg = tile_issue<CO, TW, NT>(preg, mpg, p.dz, b, x0, y0, p.B, p.H, p.W);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], b, x0, y0, p.H, p.W);
+        for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], b, x0, y0, p.B, p.H, p.W);
     }
 
-    int it = 0;
+    int it = 0, buf = 0;
+    if (DB && tile < ntiles) {
+        tile_commit<CO, TW, NT>(preg, okg, lds4, tid);
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(prex[s], okx, lds4 + TGg::N4 + s * TGx::N4, tid);
+        lds_barrier();
+    }
 #pragma unroll 1
     while (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
         STAMP(0);
-        tile_commit<CO, TW, NT>(preg, okg, lds4, tid);
+        if (!DB) {
+            tile_commit<CO, TW, NT>(preg, okg, lds4, tid);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(prex[s], okx, lds4 + TGg::N4 + s * TGx::N4, tid);
-        lds_barrier();
+            for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(prex[s], okx, lds4 + TGg::N4 + s * TGx::N4, tid);
+            lds_barrier();
+        }
+        const int GOFF = buf * (STAGE4 * 4), XOFF = GOFF + TGg::N4 * 4;      // float indices of the dz / x tiles in use
+        const float* gl = ldsf + GOFF;
+        const float* xl = ldsf + XOFF;
         STAMP(1);
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
             decode(next, nb, nx0, ny0);
-            okg = tile_issue<CO, TW, NT>(preg, mpg, p.dz, nb, nx0, ny0, p.H, p.W);
+            okg = tile_issue<CO, TW, NT>(preg, mpg, p.dz, nb, nx0, ny0, p.B, p.H, p.W);
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], nb, nx0, ny0, p.H, p.W);
+            for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], nb, nx0, ny0, p.B, p.H, p.W);
         }
 
         STAMP(2);
@@ -428,28 +459,37 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
         // ---- weight gradient: K = pixel groups (4 per MFMA); every wave takes rows ty = wave, wave + 4
 #pragma unroll 1
         for (int ty = (p.dbg & 2) ? TH : wave; ty < TH; ty += NW) {
-            const int goff = n < Nw ? (ty + 1) * LSg + TGg::HL + q * Nw + n : GCST0;
+            const int goff = n < Nw ? GOFF + (ty + 1) * LSg + TGg::HL + q * Nw + n : CST0;
             const int gstep = n < Nw ? 4 * Nw : 0;
             int aoffs[NSRC][MT];
 #pragma unroll
             for (int s = 0; s < NSRC; ++s)
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    aoffs[s][t] = stepA[t] ? s * (TGx::N4 * 4) + ty * LSx + offA[t] : offA[t];
+                    aoffs[s][t] = stepA[t] ? XOFF + s * (TGx::N4 * 4) + ty * LSx + offA[t] : offA[t];
 #pragma unroll
             for (int st = 0; st < TW / (4 * Gw); ++st) {
-                const float bv = gl[goff + st * gstep];
+                const float bv = ldsf[goff + st * gstep];
 #pragma unroll
                 for (int s = 0; s < NSRC; ++s)
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
                         // tiles whose 16 rows are all window rows use a compile-time step (immediate LDS offsets)
                         const int ao = 16 * (t + 1) <= 3 * WRw ? aoffs[s][t] + st * (4 * Gw * C) : aoffs[s][t] + st * stepA[t];
-                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xl[ao], bv, acc[s][t], 0, 0, 0);
+                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ldsf[ao], bv, acc[s][t], 0, 0, 0);
                     }
             }
         }
         STAMP(4);
+        if (DB) {
+            if (next < ntiles) {
+                tile_commit<CO, TW, NT>(preg, okg, lds4 + (buf ^ 1) * STAGE4, tid);
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s)
+                    tile_commit<C, TW, NT>(prex[s], okx, lds4 + (buf ^ 1) * STAGE4 + TGg::N4 + s * TGx::N4, tid);
+            }
+            buf ^= 1;
+        }
         lds_barrier();
         STAMP(5);
         ++it;
@@ -684,6 +724,7 @@ struct PgPlan {                      // per-model table built lazily on the firs
     int fold_chunks = 0;
     int nblocks_cap = 512;
     int nthreads = 512;
+    bool double_buffer = true;
     unsigned long long* stamps = nullptr;
 };
 
@@ -772,7 +813,7 @@ static int build_plan(Model* m, PgPlan& pl) {
         if (outs > max_out) max_out = outs;
     }
     pl.built = true;
-    if (const char* e = getenv("DNNCA_NT")) pl.nthreads = atoi(e) == 256 ? 256 : 512;   // tuning aid
+    if (const char* e = getenv("DNNCA_DB")) pl.double_buffer = atoi(e) != 0;            // tuning aid
     if (const char* e = getenv("DNNCA_NBLOCKS")) pl.nblocks_cap = atoi(e) > 0 ? atoi(e) : pl.nblocks_cap;   // tuning aid
     if (pl.folds.empty() && pl.descs.empty()) return DNNCA_OK;
     pl.fold_chunks = (max_out + 255) / 256;
@@ -828,14 +869,13 @@ bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
     a.tiles_y = (a.H + TH - 1) / TH;
     int ntiles = a.tiles_x * a.tiles_y * B;
     int nb = ntiles < pl.nblocks_cap ? ntiles : pl.nblocks_cap;
+    const bool db = pl.double_buffer && ntiles >= 3 * nb;     // LDS double buffering pays when a block walks several tiles
 #define X(c, ns, co)                                                                                            \
     if (C == c && NS == ns && CO == co) {                                                                       \
-        if (pl.nthreads == 256)                                                                                 \
+        (void)db;                                                                                               \
+        if (true)                                                                                               \
             LAUNCH(m, "pgfwd_" #c "x" #ns "_" #co, bytes, flops,                                                \
-                   hipLaunchKernelGGL((k_pgfwd<c, ns, co, 256>), dim3(nb), dim3(256), 0, m->stream, a));        \
-        else                                                                                                    \
-            LAUNCH(m, "pgfwd_" #c "x" #ns "_" #co, bytes, flops,                                                \
-                   hipLaunchKernelGGL((k_pgfwd<c, ns, co, 512>), dim3(nb), dim3(512), 0, m->stream, a));        \
+                   hipLaunchKernelGGL((k_pgfwd<c, ns, co, 512, false>), dim3(nb), dim3(512), 0, m->stream, a)); \
         return true;                                                                                            \
     }
     CONV_SHAPES(X)
@@ -884,22 +924,18 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     a.tiles_y = (a.H + TH - 1) / TH;
     int ntiles = a.tiles_x * a.tiles_y * B;
     int nb = ntiles < pl.nblocks_cap ? ntiles : pl.nblocks_cap;
+    const bool db = pl.double_buffer && ntiles >= 3 * nb;
     const double bytes = out_bytes + (o.need_din ? 2 : 1) * in_bytes;
     const double fl = (o.need_din ? 2 : 1) * flops;
 #define X(c, ns, co)                                                                                            \
     if (C == c && NS == ns && CO == co) {                                                                       \
-        if (o.need_din && pl.nthreads == 256)                                                                   \
+        (void)db;                                                                                               \
+        if (o.need_din)                                                                                    \
             LAUNCH(m, "pgbwd_" #c "x" #ns "_" #co, bytes, fl,                                                   \
-                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, true, 256>), dim3(nb), dim3(256), 0, m->stream, a));  \
-        else if (o.need_din)                                                                                    \
-            LAUNCH(m, "pgbwd_" #c "x" #ns "_" #co, bytes, fl,                                                   \
-                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, true, 512>), dim3(nb), dim3(512), 0, m->stream, a));  \
-        else if (pl.nthreads == 256)                                                                            \
-            LAUNCH(m, "pgbwd_w_" #c "x" #ns "_" #co, bytes, fl,                                                 \
-                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, false, 256>), dim3(nb), dim3(256), 0, m->stream, a)); \
+                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, true, 512, false>), dim3(nb), dim3(512), 0, m->stream, a)); \
         else                                                                                                    \
             LAUNCH(m, "pgbwd_w_" #c "x" #ns "_" #co, bytes, fl,                                                 \
-                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, false, 512>), dim3(nb), dim3(512), 0, m->stream, a)); \
+                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, false, 512, false>), dim3(nb), dim3(512), 0, m->stream, a)); \
         return true;                                                                                            \
     }
     CONV_SHAPES(X)
