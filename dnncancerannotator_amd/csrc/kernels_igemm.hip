@@ -1,0 +1,368 @@
+// kernels_igemm.hip -- implicit-GEMM 3x3 convolutions on the fp32 matrix cores for channel counts that are multiples
+// of 16 (configs/mulmo_unet.yaml: 16..384, configs/unet_big.yaml: 64..1024).  Here the contraction is dense:
+//     forward / data gradient:  M = pixels (block tile 8 rows x 16 px), N = output channels (16*NN per block),
+//                               K = 9 taps x input channels, walked in chunks of CK = 16 input channels;
+//     weight gradient:          M = 16 input channels, N = 16*NN output channels, K = pixels, all 9 taps at once
+//                               (accumulators live in registers while a persistent block walks its pixel tiles).
+// Per chunk a block stages the (8+2) x (16+2) x CK input patch and the 9 x CK x 16*NN weight slab in LDS once and issues
+// 288 (NN = 4) MFMAs per wave between two barriers; the decoder concat is two sources, never materialised; bias +
+// activation (forward) or act' mask + accumulate + destination split (data gradient) are fused into the store.
+// The data gradient is the forward kernel on a transposed + flipped copy of the weights (k_ig_flip, once per step).
+#include "fast.h"
+#include "kernels.h"
+
+namespace dnnca {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace ig {
+
+constexpr int TY = 8, TX = 16;          // block tile: 8 rows x 16 pixels = 128 GEMM rows, 32 per wave
+constexpr int CK = 16;                  // input channels per staged chunk
+constexpr int CKP = CK + 4;             // LDS pixel stride of the input patch (floats)
+constexpr int PATCH = (TY + 2) * (TX + 2);
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct ConvArgs {
+    const float* src[2];     // dense NHWC sources; chunk cc comes from src[cc >= c_src0]
+    int c_src0, c_src1;      // channels of the two sources (c_src1 = 0: one source)
+    const float* w;          // [9][Cin][Cout] (forward: the Keras kernel; data gradient: flipped/transposed copy)
+    const float* bias;       // forward: Cout floats (nullptr: none)
+    float* dst[2];           // output tensors; N-tiles below n_dst0 channels go to dst[0], the rest to dst[1]
+    int n_dst0, n_dst1;      // channels of the two destinations
+    const float* mask[2];    // data gradient: multiply by act'(mask tensor) (nullptr: no mask)
+    int acc[2];              // data gradient: accumulate into dst
+    int B, H, W;
+    int tiles_x, tiles_y;
+    float alpha;             // forward: activation slope (<0 none); data gradient: slope of the masked activation
+};
+
+// MODE 0 forward, MODE 1 data gradient
+template <int NN, int MODE>
+__global__ __launch_bounds__(256) void k_ig_conv(ConvArgs p) {
+    constexpr int NT = 16 * NN, BSTR = NT + 16;        // weight slab row stride (floats): conflict-free B reads
+    __shared__ float a_lds[PATCH * CKP];
+    __shared__ float b_lds[9 * CK * BSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int cin = p.c_src0 + p.c_src1, cout = p.n_dst0 + p.n_dst1;
+    const int tile = blockIdx.x, bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = bx * TX, y0 = by * TY;
+    const int co0 = blockIdx.y * NT;
+
+    f32x4 acc[2][NN];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int cc = 0; cc < cin; cc += CK) {
+        const bool second = cc >= p.c_src0;
+        const float* src = second ? p.src[1] : p.src[0];
+        const int cs = second ? p.c_src1 : p.c_src0, c0 = second ? cc - p.c_src0 : cc;
+        lds_barrier();        // the previous chunk's reads are complete
+        // input patch: PATCH pixels x 4 float4 (16 channels), zero outside the image
+        for (int i = tid; i < PATCH * (CK / 4); i += 256) {
+            const int px = i >> 2, c4 = i & 3;
+            const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(src + (((size_t)b * p.H + iy) * p.W + ix) * cs + c0 + 4 * c4);
+            *reinterpret_cast<float4*>(a_lds + px * CKP + 4 * c4) = v;
+        }
+        // weight slab: 9 taps x CK rows x NT columns
+        for (int i = tid; i < 9 * CK * (NT / 4); i += 256) {
+            const int n4 = i % (NT / 4), rk = i / (NT / 4);      // rk = tap * CK + k
+            const int tap = rk / CK, k = rk - tap * CK;
+            const float4 v = *reinterpret_cast<const float4*>(p.w + ((size_t)tap * cin + cc + k) * cout + co0 + 4 * n4);
+            *reinterpret_cast<float4*>(b_lds + rk * BSTR + 4 * n4) = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int k4 = 0; k4 < CK / 4; ++k4) {
+                float bv[NN];
+#pragma unroll
+                for (int j = 0; j < NN; ++j) bv[j] = b_lds[(tap * CK + 4 * k4 + q) * BSTR + 16 * j + m16];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float av = a_lds[((2 * wave + r + dy) * (TX + 2) + m16 + dx) * CKP + 4 * k4 + q];
+#pragma unroll
+                    for (int j = 0; j < NN; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[r][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: D[pixel 4q+i][channel 16j + m16]
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int y = y0 + 2 * wave + r;
+        if (y >= p.H) continue;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            const int co = co0 + 16 * j + m16;
+            const int which = co >= p.n_dst0;
+            const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co - p.n_dst0 : co;
+            const float bias = (MODE == 0 && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = x0 + 4 * q + i;
+                if (x >= p.W) continue;
+                const size_t o = (((size_t)b * p.H + y) * p.W + x) * cw + cl;
+                float v = acc[r][j][i];
+                if (MODE == 0) {
+                    v += bias;
+                    v = p.alpha < 0.f ? v : (v > 0.f ? v : p.alpha * v);
+                } else {
+                    if (p.acc[which]) v += p.dst[which][o];
+                    if (p.mask[which]) v *= p.mask[which][o] > 0.f ? 1.0f : p.alpha;
+                }
+                p.dst[which][o] = v;
+            }
+        }
+    }
+}
+
+// flipped + transposed kernels for the data gradient: wT[t][co][ci] = w[8 - t][ci][co]
+struct FlipDesc {
+    int w_off, cin, cout;
+};
+__global__ void k_ig_flip(const FlipDesc* __restrict__ descs, const float* __restrict__ params, float* __restrict__ flipped) {
+    const FlipDesc d = descs[blockIdx.y];
+    const int n = 9 * d.cin * d.cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ci = i % d.cin, co = (i / d.cin) % d.cout, t = i / (d.cin * d.cout);
+        flipped[d.w_off + i] = params[d.w_off + ((8 - t) * d.cin + ci) * d.cout + co];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct WgArgs {
+    const float* x;          // one source, dense NHWC, cs channels
+    const float* dz;         // dense NHWC, cout channels
+    float* dw;               // [9][cin_total][cout] gradient (atomic accumulation; zeroed by the caller)
+    float* dbias;            // cout floats or nullptr
+    int cs, ci_off, cin_total, cout;
+    int B, H, W;
+    int tiles_x, tiles_y, psplit;
+};
+
+// grid: x = pixel split, y = input-channel chunk (16), z = output-channel tile (16*NN)
+template <int NN>
+__global__ __launch_bounds__(256) void k_ig_wgrad(WgArgs p) {
+    constexpr int NT = 16 * NN, GSTR = NT + 4;
+    __shared__ float x_lds[PATCH * CKP];
+    __shared__ float g_lds[TY * TX * GSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int c0 = blockIdx.y * CK, co0 = blockIdx.z * NT;
+    const bool do_bias = p.dbias && blockIdx.y == 0;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+
+    f32x4 acc[9][NN];
+    f32x4 accb[NN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NN; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.psplit) {
+        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+        const int x0 = bx * TX, y0 = by * TY;
+        lds_barrier();
+        for (int i = tid; i < PATCH * (CK / 4); i += 256) {
+            const int px = i >> 2, c4 = i & 3;
+            const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.cs + c0 + 4 * c4);
+            *reinterpret_cast<float4*>(x_lds + px * CKP + 4 * c4) = v;
+        }
+        for (int i = tid; i < TY * TX * (NT / 4); i += 256) {
+            const int n4 = i % (NT / 4), px = i / (NT / 4);
+            const int ly = px / TX, lx = px - ly * TX;
+            const int iy = y0 + ly, ix = x0 + lx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy < p.H && ix < p.W)
+                v = *reinterpret_cast<const float4*>(p.dz + (((size_t)b * p.H + iy) * p.W + ix) * p.cout + co0 + 4 * n4);
+            *reinterpret_cast<float4*>(g_lds + px * GSTR + 4 * n4) = v;
+        }
+        lds_barrier();
+        // every wave: 2 rows of the tile = 8 K-steps of 4 pixels
+#pragma unroll 1
+        for (int ks = 0; ks < 8; ++ks) {
+            const int row = 2 * wave + (ks >> 2), px0 = (ks & 3) * 4;
+            float bv[NN];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) bv[j] = g_lds[(row * TX + px0 + q) * GSTR + 16 * j + m16];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float av = x_lds[((row + t / 3) * (TX + 2) + px0 + q + t % 3) * CKP + m16];
+#pragma unroll
+                for (int j = 0; j < NN; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[t][j], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < NN; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bv[j], accb[j], 0, 0, 0);
+            }
+        }
+    }
+    // D[ci = 4q + i][co = 16j + m16] -> dW[tap][ci_off + c0 + ci][co0 + co]; four waves add their partial sums
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(p.dw + ((size_t)t * p.cin_total + p.ci_off + c0 + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
+    if (do_bias && q == 0) {
+#pragma unroll
+        for (int j = 0; j < NN; ++j) atomicAdd(p.dbias + co0 + 16 * j + m16, accb[j][0]);     // row 0 of the all-ones A
+    }
+}
+
+}  // namespace ig
+
+// ================================================================================================ host side
+struct IgPlan {
+    bool built = false;
+    std::vector<ig::FlipDesc> flips;
+    ig::FlipDesc* flips_dev = nullptr;
+    float* flipped = nullptr;        // same layout / offsets as the parameter vector (only conv kernels are filled)
+    int max_w = 0;
+};
+static std::map<Model*, IgPlan> g_ig;
+
+void ig_release(Model* m) { g_ig.erase(m); }
+
+static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
+
+bool ig_conv_supported(const Model* m, const Op& o) {
+    if (o.type != OP_CONV || o.k != 3 || m->desc.dtype != DNNCA_F32) return false;
+    if (!dense(o.inA.d) || !dense(o.inB.d) || !dense(o.out.d)) return false;
+    const int CA = o.inA.d.C, CB = o.inB.d.C, CO = o.out.d.C;
+    return CA % 16 == 0 && CB % 16 == 0 && CO % 16 == 0 && CA > 0;
+}
+
+static int pick_nn(int cout) { return cout % 64 == 0 ? 4 : (cout % 32 == 0 ? 2 : 1); }
+
+int ig_prepare(Model* m) {
+    if (m->desc.flags & 1) return DNNCA_OK;
+    IgPlan& pl = g_ig[m];
+    if (!pl.built) {
+        pl.built = true;
+        for (const Op& o : m->ops) {
+            if (!ig_conv_supported(m, o) || !o.need_din) continue;
+            ig::FlipDesc d{(int)o.w_off, o.inA.d.C + o.inB.d.C, o.out.d.C};
+            pl.flips.push_back(d);
+            int n = 9 * d.cin * d.cout;
+            if (n > pl.max_w) pl.max_w = n;
+        }
+        if (!pl.flips.empty()) {
+            DN_TRY(m->alloc((void**)&pl.flips_dev, pl.flips.size() * sizeof(ig::FlipDesc)));
+            DN_TRY(m->alloc((void**)&pl.flipped, (size_t)m->nT * 4));
+            HIP_TRY(hipMemcpyAsync(pl.flips_dev, pl.flips.data(), pl.flips.size() * sizeof(ig::FlipDesc), hipMemcpyHostToDevice, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+    }
+    return DNNCA_OK;
+}
+
+// once per backward pass: the data-gradient kernels read flipped/transposed weights
+int ig_begin_backward(Model* m) {
+    if (m->desc.flags & 1) return DNNCA_OK;
+    IgPlan& pl = g_ig[m];
+    if (pl.flips.empty()) return DNNCA_OK;
+    int bx = (pl.max_w + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    LAUNCH(m, "ig_flip", 8.0 * m->nT, 0,
+           hipLaunchKernelGGL(ig::k_ig_flip, dim3(bx, (unsigned)pl.flips.size()), dim3(256), 0, m->stream, pl.flips_dev, m->p, pl.flipped));
+    return DNNCA_OK;
+}
+
+template <int MODE>
+static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* name, double bytes, double flops) {
+    const int nn = pick_nn(cout);
+    dim3 grid(a.tiles_x * a.tiles_y * a.B, cout / (16 * nn));
+    if (nn == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv<4, MODE>), grid, dim3(256), 0, m->stream, a));
+    else if (nn == 2) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv<2, MODE>), grid, dim3(256), 0, m->stream, a));
+    else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv<1, MODE>), grid, dim3(256), 0, m->stream, a));
+}
+
+bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
+    if (!ig_conv_supported(m, o)) return false;
+    ig::ConvArgs a{};
+    a.src[0] = o.inA.d.p; a.src[1] = o.inB.d.p;
+    a.c_src0 = o.inA.d.C; a.c_src1 = o.inB.d.C;
+    a.w = m->p + o.w_off;
+    a.bias = m->p + o.b_off;
+    a.dst[0] = o.out.d.p; a.n_dst0 = o.out.d.C; a.n_dst1 = 0;
+    a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
+    a.tiles_x = (a.W + ig::TX - 1) / ig::TX;
+    a.tiles_y = (a.H + ig::TY - 1) / ig::TY;
+    a.alpha = o.alpha;
+    launch_ig<0>(m, a, o.out.d.C, "ig_conv_fwd", bytes, flops);
+    return true;
+}
+
+bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops) {
+    if (!ig_conv_supported(m, o)) return false;
+    IgPlan& pl = g_ig[m];
+    const int CA = o.inA.d.C, CB = o.inB.d.C, CO = o.out.d.C;
+    if (o.alpha >= 0.f && !o.premasked)
+        LAUNCH(m, "g_act_bwd", 3 * out_bytes, out_bytes / 4,
+               g_act_bwd(m->stream, (size_t)B * o.out.d.H * o.out.d.W * CO, o.out.g.p, o.out.d.p, o.alpha));
+    const int tiles_x = (o.out.d.W + ig::TX - 1) / ig::TX, tiles_y = (o.out.d.H + ig::TY - 1) / ig::TY;
+    // weight (+bias) gradient, one launch per source
+    for (int s = 0; s < (CB ? 2 : 1); ++s) {
+        ig::WgArgs w{};
+        w.x = s == 0 ? o.inA.d.p : o.inB.d.p;
+        w.dz = o.out.g.p;
+        w.dw = m->g + o.w_off;
+        w.dbias = s == 0 ? m->g + o.b_off : nullptr;
+        w.cs = s == 0 ? CA : CB;
+        w.ci_off = s == 0 ? 0 : CA;
+        w.cin_total = CA + CB;
+        w.cout = CO;
+        w.B = B; w.H = o.out.d.H; w.W = o.out.d.W;
+        w.tiles_x = tiles_x; w.tiles_y = tiles_y;
+        const int nn = pick_nn(CO);
+        const int combos = (w.cs / ig::CK) * (CO / (16 * nn));
+        const int ntiles = tiles_x * tiles_y * B;
+        int psplit = (1024 + combos - 1) / combos;
+        if (psplit > ntiles) psplit = ntiles;
+        if (psplit < 1) psplit = 1;
+        w.psplit = psplit;
+        dim3 grid(psplit, w.cs / ig::CK, CO / (16 * nn));
+        const double bb = (out_bytes + in_bytes) / (CB ? 2 : 1), ff = flops / (CB ? 2 : 1);
+        if (nn == 4) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<4>), grid, dim3(256), 0, m->stream, w));
+        else if (nn == 2) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<2>), grid, dim3(256), 0, m->stream, w));
+        else LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<1>), grid, dim3(256), 0, m->stream, w));
+    }
+    if (o.need_din) {
+        ig::ConvArgs a{};
+        a.src[0] = o.out.g.p; a.c_src0 = CO; a.c_src1 = 0;
+        a.w = pl.flipped + o.w_off;
+        a.dst[0] = o.inA.g.p; a.dst[1] = o.inB.g.p;
+        a.n_dst0 = CA; a.n_dst1 = CB;
+        a.mask[0] = o.maskA ? o.inA.d.p : nullptr;
+        a.mask[1] = o.maskB ? o.inB.d.p : nullptr;
+        a.acc[0] = o.accA; a.acc[1] = o.accB;
+        a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
+        a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+        a.alpha = o.mask_alpha;
+        launch_ig<1>(m, a, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
+    }
+    return true;
+}
+
+}  // namespace dnnca

@@ -30,6 +30,7 @@ static constexpr float kBnEps = 1e-3f;
 
 Model::~Model() {
     fast_release(this);
+    ig_release(this);
     for (void* a : allocs) (void)hipFree(a);
     for (auto& r : recs) {
         (void)hipEventDestroy(r.a);
@@ -368,6 +369,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
         }
     xin.d.p = const_cast<float*>(x_dev);
     DN_TRY(fast_prepare(this));
+    DN_TRY(ig_prepare(this));
 
     for (Op& o : ops) {
         switch (o.type) {
@@ -375,7 +377,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 int Cin = o.inA.d.C + o.inB.d.C;
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d) + nelem(B, o.out.d));
                 double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
-                if (!generic && fast_conv_fwd(this, B, o, bytes, flops)) break;
+                if (!generic && (fast_conv_fwd(this, B, o, bytes, flops) || ig_conv_fwd(this, B, o, bytes, flops))) break;
                 LAUNCH(this, "g_conv_fwd", bytes, flops,
                        g_conv_fwd(stream, B, o.inA.d, o.inB.d, p + o.w_off, p + o.b_off, o.out.d, o.k, o.alpha));
                 break;
@@ -452,6 +454,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                g_loss(stream, npix, logits, y_dev, cfg, (double)npix, scalars, backward ? dlogits : nullptr, prob, gscale));
     }
     if (backward) {
+        DN_TRY(ig_begin_backward(this));
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             Op& o = ops[i];
             switch (o.type) {
@@ -467,7 +470,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     int Cin = o.inA.d.C + o.inB.d.C;
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d));
                     double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
-                    if (!generic && fast_conv_bwd(this, B, o, ob, ib, flops)) break;
+                    if (!generic && (fast_conv_bwd(this, B, o, ob, ib, flops) || ig_conv_bwd(this, B, o, ob, ib, flops))) break;
                     if (o.maskA || o.maskB) { set_error("internal: masked conv gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     if (o.alpha >= 0.f && !o.premasked)
                         LAUNCH(this, "g_act_bwd", 3 * ob, ob / 4,
