@@ -21,6 +21,8 @@ bool fast_tconv_supported(const Model* m, const Op& o);
 bool fast_head_supported(const Model* m, const Op& o);
 bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cfg& cfg, float gscale, double bytes);
 bool fast_label_stats(Model* m, size_t n, const float* y);
+bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps);
+bool fast_bn_bwd(Model* m, int B, Op& o);
 void fast_plan_masks(Model* m);
 // implicit-GEMM MFMA path for channel counts that are multiples of 16 (kernels_igemm.hip)
 bool ig_conv_supported(const Model* m, const Op& o);
@@ -28,6 +30,9 @@ int ig_prepare(Model* m);
 int ig_begin_backward(Model* m);
 void ig_release(Model* m);
 bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops);
-bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);   // decides maskA/maskB/premasked for every op (static per model)
+bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
+bool ig_tconv_supported(const Model* m, const Op& o);
+bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops);
+bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);   // decides maskA/maskB/premasked for every op (static per model)
 
 }  // namespace dnnca

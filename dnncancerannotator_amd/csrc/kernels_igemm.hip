@@ -230,6 +230,201 @@ __global__ __launch_bounds__(256) void k_ig_wgrad(WgArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ transposed conv 2x2/2
+// Conv2DTranspose(k = s = 2) is four independent 1x1 GEMMs, one per output parity (a, e): out[2i+a][2j+e] = W[a][e] . in[i][j].
+// Kernel layout [a][e][Cout][Cin].  M = 128 consecutive input pixels per block (32 per wave).
+struct TcArgs {
+    const float* in;         // [B,H,W,Cin]
+    const float* w;          // [2][2][Cout][Cin]
+    const float* bias;
+    float* out;              // forward: [B,2H,2W,Cout]
+    const float* dout;       // backward: gradient of out
+    float* din;              // data gradient destination
+    const float* mask;       // multiply din by act'(mask) (nullptr: none)
+    float* dw;               // weight gradient (atomic accumulation)
+    float* dbias;
+    int acc;
+    int cin, cout;
+    int H, W;                // input height / width
+    int npix;                // B*H*W
+    int psplit;
+    float alpha;
+};
+
+__device__ __forceinline__ size_t tc_outpix(int p, int a, int e, int H, int W) {
+    const int j = p % W, bi = p / W;          // bi = b*H + i
+    return ((size_t)bi * 2 + a) * (2 * W) + 2 * j + e;
+}
+
+template <int NN>
+__global__ __launch_bounds__(256) void k_ig_tconv_fwd(TcArgs p) {
+    constexpr int NT = 16 * NN, BSTR = NT + 16;
+    __shared__ float a_lds[128 * CKP];
+    __shared__ float b_lds[CK * BSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int p0 = blockIdx.x * 128, co0 = blockIdx.y * NT, ae = blockIdx.z, a = ae >> 1, e = ae & 1;
+    f32x4 acc[2][NN];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cc = 0; cc < p.cin; cc += CK) {
+        lds_barrier();
+        for (int i = tid; i < 128 * 4; i += 256) {
+            const int px = i >> 2, c4 = i & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + px < p.npix) v = *reinterpret_cast<const float4*>(p.in + (size_t)(p0 + px) * p.cin + cc + 4 * c4);
+            *reinterpret_cast<float4*>(a_lds + px * CKP + 4 * c4) = v;
+        }
+        for (int i = tid; i < NT * 4; i += 256) {       // B[k = ci][n = co] = W[a][e][co][ci]: transposed while staging
+            const int n = i >> 2, k4 = i & 3;
+            const float4 v = *reinterpret_cast<const float4*>(p.w + ((size_t)ae * p.cout + co0 + n) * p.cin + cc + 4 * k4);
+            b_lds[(4 * k4 + 0) * BSTR + n] = v.x;
+            b_lds[(4 * k4 + 1) * BSTR + n] = v.y;
+            b_lds[(4 * k4 + 2) * BSTR + n] = v.z;
+            b_lds[(4 * k4 + 3) * BSTR + n] = v.w;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int k4 = 0; k4 < CK / 4; ++k4) {
+            float bv[NN];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) bv[j] = b_lds[(4 * k4 + q) * BSTR + 16 * j + m16];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float av = a_lds[(32 * wave + 16 * r + m16) * CKP + 4 * k4 + q];
+#pragma unroll
+                for (int j = 0; j < NN; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[r][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = p0 + 32 * wave + 16 * r + 4 * q + i;
+            if (px >= p.npix) continue;
+            float* op = p.out + tc_outpix(px, a, e, p.H, p.W) * p.cout + co0 + m16;
+#pragma unroll
+            for (int j = 0; j < NN; ++j) op[16 * j] = acc[r][j][i] + p.bias[co0 + 16 * j + m16];
+        }
+}
+
+// data gradient: din[p][ci] = sum_{a,e,co} dout[out(p,a,e)][co] * W[a][e][co][ci]   (N = ci tile, K = 4 x Cout)
+template <int NN>
+__global__ __launch_bounds__(256) void k_ig_tconv_dgrad(TcArgs p) {
+    constexpr int NT = 16 * NN, BSTR = NT + 16;
+    __shared__ float a_lds[128 * CKP];
+    __shared__ float b_lds[CK * BSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int p0 = blockIdx.x * 128, n0 = blockIdx.y * NT;
+    f32x4 acc[2][NN];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kc = 0; kc < 4 * p.cout; kc += CK) {
+        const int ae = kc / p.cout, cc = kc - ae * p.cout, a = ae >> 1, e = ae & 1;
+        lds_barrier();
+        for (int i = tid; i < 128 * 4; i += 256) {
+            const int px = i >> 2, c4 = i & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + px < p.npix) v = *reinterpret_cast<const float4*>(p.dout + tc_outpix(p0 + px, a, e, p.H, p.W) * p.cout + cc + 4 * c4);
+            *reinterpret_cast<float4*>(a_lds + px * CKP + 4 * c4) = v;
+        }
+        for (int i = tid; i < CK * (NT / 4); i += 256) {
+            const int n4 = i % (NT / 4), k = i / (NT / 4);
+            const float4 v = *reinterpret_cast<const float4*>(p.w + ((size_t)ae * p.cout + cc + k) * p.cin + n0 + 4 * n4);
+            *reinterpret_cast<float4*>(b_lds + k * BSTR + 4 * n4) = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int k4 = 0; k4 < CK / 4; ++k4) {
+            float bv[NN];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) bv[j] = b_lds[(4 * k4 + q) * BSTR + 16 * j + m16];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float av = a_lds[(32 * wave + 16 * r + m16) * CKP + 4 * k4 + q];
+#pragma unroll
+                for (int j = 0; j < NN; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[r][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = p0 + 32 * wave + 16 * r + 4 * q + i;
+            if (px >= p.npix) continue;
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                const size_t o = (size_t)px * p.cin + n0 + 16 * j + m16;
+                float v = acc[r][j][i];
+                if (p.acc) v += p.din[o];
+                if (p.mask) v *= p.mask[o] > 0.f ? 1.0f : p.alpha;
+                p.din[o] = v;
+            }
+        }
+}
+
+// weight gradient: dW[a][e][co][ci] = sum_p dout[out(p,a,e)][co] * in[p][ci]   (M = 16 co, N = ci tile, K = pixels)
+// grid: x = pixel split, y = co chunk (16), z = 4 * (Cin / NT) + ...
+template <int NN>
+__global__ __launch_bounds__(256) void k_ig_tconv_wgrad(TcArgs p) {
+    constexpr int NT = 16 * NN, XSTR = NT + 4;
+    __shared__ float g_lds[128 * CKP];
+    __shared__ float x_lds[128 * XSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int co0 = blockIdx.y * CK;
+    const int ntn = p.cin / NT, ae = blockIdx.z / ntn, n0 = (blockIdx.z % ntn) * NT, a = ae >> 1, e = ae & 1;
+    const bool do_bias = p.dbias && n0 == 0;
+    f32x4 acc[NN], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = (p.npix + 127) / 128;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.psplit) {
+        const int p0 = tile * 128;
+        lds_barrier();
+        for (int i = tid; i < 128 * 4; i += 256) {
+            const int px = i >> 2, c4 = i & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + px < p.npix) v = *reinterpret_cast<const float4*>(p.dout + tc_outpix(p0 + px, a, e, p.H, p.W) * p.cout + co0 + 4 * c4);
+            *reinterpret_cast<float4*>(g_lds + px * CKP + 4 * c4) = v;
+        }
+        for (int i = tid; i < 128 * (NT / 4); i += 256) {
+            const int n4 = i % (NT / 4), px = i / (NT / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + px < p.npix) v = *reinterpret_cast<const float4*>(p.in + (size_t)(p0 + px) * p.cin + n0 + 4 * n4);
+            *reinterpret_cast<float4*>(x_lds + px * XSTR + 4 * n4) = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int px = 32 * wave + 4 * ks + q;
+            const float av = g_lds[px * CKP + m16];
+#pragma unroll
+            for (int j = 0; j < NN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x_lds[px * XSTR + 16 * j + m16], acc[j], 0, 0, 0);
+            if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.0f, accb, 0, 0, 0);
+        }
+    }
+    // D[co = 4q + i][ci = 16j + m16]
+#pragma unroll
+    for (int j = 0; j < NN; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            atomicAdd(p.dw + ((size_t)ae * p.cout + co0 + 4 * q + i) * p.cin + n0 + 16 * j + m16, acc[j][i]);
+    if (do_bias && m16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(p.dbias + co0 + 4 * q + i, accb[i]);
+    }
+}
+
 }  // namespace ig
 
 // ================================================================================================ host side
@@ -361,6 +556,67 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         a.tiles_x = tiles_x; a.tiles_y = tiles_y;
         a.alpha = o.mask_alpha;
         launch_ig<1>(m, a, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
+    }
+    return true;
+}
+
+bool ig_tconv_supported(const Model* m, const Op& o) {
+    if (o.type != OP_TCONV || o.k != 2 || m->desc.dtype != DNNCA_F32) return false;
+    if (!dense(o.inA.d) || !dense(o.out.d)) return false;
+    return o.inA.d.C % 16 == 0 && o.out.d.C % 16 == 0;
+}
+
+static ig::TcArgs tc_args(Model* m, int B, Op& o) {
+    ig::TcArgs a{};
+    a.in = o.inA.d.p;
+    a.w = m->p + o.w_off;
+    a.bias = m->p + o.b_off;
+    a.out = o.out.d.p;
+    a.dout = o.out.g.p;
+    a.din = o.inA.g.p;
+    a.mask = o.maskA ? o.inA.d.p : nullptr;
+    a.dw = m->g + o.w_off;
+    a.dbias = m->g + o.b_off;
+    a.acc = o.accA;
+    a.cin = o.inA.d.C; a.cout = o.out.d.C;
+    a.H = o.inA.d.H; a.W = o.inA.d.W;
+    a.npix = B * a.H * a.W;
+    a.alpha = o.mask_alpha;
+    return a;
+}
+
+bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
+    if (!ig_tconv_supported(m, o)) return false;
+    ig::TcArgs a = tc_args(m, B, o);
+    const int nn = pick_nn(a.cout);
+    dim3 grid((a.npix + 127) / 128, a.cout / (16 * nn), 4);
+    if (nn == 4) LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd<4>), grid, dim3(256), 0, m->stream, a));
+    else if (nn == 2) LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd<2>), grid, dim3(256), 0, m->stream, a));
+    else LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd<1>), grid, dim3(256), 0, m->stream, a));
+    return true;
+}
+
+bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops) {
+    if (!ig_tconv_supported(m, o)) return false;
+    ig::TcArgs a = tc_args(m, B, o);
+    {
+        const int nn = pick_nn(a.cin);
+        const int ntiles = (a.npix + 127) / 128;
+        const int combos = (a.cout / 16) * 4 * (a.cin / (16 * nn));
+        int psplit = (1024 + combos - 1) / combos;
+        if (psplit > ntiles) psplit = ntiles;
+        a.psplit = psplit < 1 ? 1 : psplit;
+        dim3 grid(a.psplit, a.cout / 16, 4 * (a.cin / (16 * nn)));
+        if (nn == 4) LAUNCH(m, "ig_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad<4>), grid, dim3(256), 0, m->stream, a));
+        else if (nn == 2) LAUNCH(m, "ig_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad<2>), grid, dim3(256), 0, m->stream, a));
+        else LAUNCH(m, "ig_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad<1>), grid, dim3(256), 0, m->stream, a));
+    }
+    {
+        const int nn = pick_nn(a.cin);
+        dim3 grid((a.npix + 127) / 128, a.cin / (16 * nn));
+        if (nn == 4) LAUNCH(m, "ig_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_dgrad<4>), grid, dim3(256), 0, m->stream, a));
+        else if (nn == 2) LAUNCH(m, "ig_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_dgrad<2>), grid, dim3(256), 0, m->stream, a));
+        else LAUNCH(m, "ig_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_dgrad<1>), grid, dim3(256), 0, m->stream, a));
     }
     return true;
 }

@@ -999,7 +999,7 @@ void fast_plan_masks(Model* m) {
         bool can = false;
         if (c.type == OP_CONV) can = (conv_supported(m, c) || ig_conv_supported(m, c)) && c.need_din;
         else if (c.type == OP_POOL) can = fast_pool_supported(m, c);
-        else if (c.type == OP_TCONV) can = fast_tconv_supported(m, c);
+        else if (c.type == OP_TCONV) can = fast_tconv_supported(m, c) || ig_tconv_supported(m, c);
         else if (c.type == OP_HEAD) can = fast_head_supported(m, c);
         if (!can) continue;
         (which ? c.maskB : c.maskA) = true;

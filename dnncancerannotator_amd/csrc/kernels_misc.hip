@@ -488,3 +488,184 @@ bool fast_label_stats(Model* m, size_t n, const float* y) {
 }
 
 }  // namespace dnnca
+
+// ================================================================================================ batch normalisation
+// Tuned BatchNormalization for C % 4 == 0 with (C/4) | 256 (16..1024 channels): one thread owns a 4-channel group of a
+// pixel (16-byte loads), the 256/(C/4) pixel lanes of a block stride over its pixel range, partial sums meet in LDS and
+// leave the block as ONE atomic per channel.  Statistics are raw moments (sum, sum of squares) accumulated in double at
+// block level; g_bn_finalize turns them into mean / biased variance.
+namespace dnnca {
+
+static inline bool bn_fast_ok(const View& x) { return x.ps == x.C && x.C % 4 == 0 && 256 % (x.C / 4) == 0 && x.C >= 16; }
+
+__global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float* __restrict__ x, int C, double* __restrict__ ws) {
+    __shared__ double red[256][8];
+    const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
+    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+    float s[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    int cnt = 0;
+    for (size_t p = p0 + pl; p < p1; p += PL) {
+        const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * cq);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        sq[0] = fmaf(v.x, v.x, sq[0]); sq[1] = fmaf(v.y, v.y, sq[1]); sq[2] = fmaf(v.z, v.z, sq[2]); sq[3] = fmaf(v.w, v.w, sq[3]);
+        if (++cnt == 64) {          // bound the float partials' rounding error
+            for (int i = 0; i < 4; ++i) { ds[i] += s[i]; dq[i] += sq[i]; s[i] = 0.f; sq[i] = 0.f; }
+            cnt = 0;
+        }
+    }
+    for (int i = 0; i < 4; ++i) { ds[i] += s[i]; dq[i] += sq[i]; }
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = ds[i]; red[threadIdx.x][4 + i] = dq[i]; }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < PL; ++l)
+            for (int i = 0; i < 8; ++i) a[i] += red[l * G + threadIdx.x][i];
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(ws + 4 * threadIdx.x + i, a[i]);
+            atomicAdd(ws + C + 4 * threadIdx.x + i, a[4 + i]);
+        }
+    }
+}
+
+// raw moments -> coefficients (and the moving statistics in training): same contract as g_bn_finalize
+__global__ void k_bn_finalize_raw(int C, double n, const double* __restrict__ ws, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* __restrict__ mmean, float* __restrict__ mvar,
+                                  float* __restrict__ coef, float momentum, float eps) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean_d = ws[c] / n;
+    double var_d = ws[C + c] / n - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, var = (float)var_d;
+    const float unbiased = (float)(var_d * (n > 1.0 ? n / (n - 1.0) : 1.0));
+    mmean[c] = mmean[c] * momentum + mean * (1.f - momentum);
+    mvar[c] = mvar[c] * momentum + unbiased * (1.f - momentum);
+    const float inv = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * inv;
+    coef[c] = sc;
+    coef[C + c] = beta[c] - mean * sc;
+    coef[2 * C + c] = mean;
+    coef[3 * C + c] = inv;
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* __restrict__ x, float* __restrict__ y, int C,
+                                                       int yps, const float* __restrict__ coef) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int G = C / 4, cq = (int)(i % G);
+    const size_t p = i / G;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(coef + 4 * cq), sh = *reinterpret_cast<const float4*>(coef + C + 4 * cq);
+    float4 o;
+    o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+    *reinterpret_cast<float4*>(y + p * yps + 4 * cq) = o;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const float* __restrict__ x, const float* __restrict__ dy,
+                                                            int C, int dps, const float* __restrict__ coef,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[256][8];
+    const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
+    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
+    float sg[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    for (size_t p = p0 + pl; p < p1; p += PL) {
+        const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * cq);
+        const float4 d = *reinterpret_cast<const float4*>(dy + p * dps + 4 * cq);
+        sg[0] = fmaf(d.x, (v.x - mean.x) * inv.x, sg[0]); sg[1] = fmaf(d.y, (v.y - mean.y) * inv.y, sg[1]);
+        sg[2] = fmaf(d.z, (v.z - mean.z) * inv.z, sg[2]); sg[3] = fmaf(d.w, (v.w - mean.w) * inv.w, sg[3]);
+        sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
+    }
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = sg[i]; red[threadIdx.x][4 + i] = sb[i]; }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < PL; ++l)
+            for (int i = 0; i < 8; ++i) a[i] += red[l * G + threadIdx.x][i];
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(dgamma + 4 * threadIdx.x + i, a[i]);
+            atomicAdd(dbeta + 4 * threadIdx.x + i, a[4 + i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int C, int dps, int acc,
+                                                           const float* __restrict__ coef, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           float inv_n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int G = C / 4, cq = (int)(i % G);
+    const size_t p = i / G;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 d = *reinterpret_cast<const float4*>(dy + p * dps + 4 * cq);
+    const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * cq);
+    const float4 dg = *reinterpret_cast<const float4*>(dgamma + 4 * cq), db = *reinterpret_cast<const float4*>(dbeta + 4 * cq);
+    float4 r;
+    r.x = g.x * inv.x * (d.x - inv_n * (db.x + (v.x - mean.x) * inv.x * dg.x));
+    r.y = g.y * inv.y * (d.y - inv_n * (db.y + (v.y - mean.y) * inv.y * dg.y));
+    r.z = g.z * inv.z * (d.z - inv_n * (db.z + (v.z - mean.z) * inv.z * dg.z));
+    r.w = g.w * inv.w * (d.w - inv_n * (db.w + (v.w - mean.w) * inv.w * dg.w));
+    float4* o = reinterpret_cast<float4*>(dx) + i;
+    if (acc) {
+        const float4 t = *o;
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    *o = r;
+}
+
+static unsigned bn_blocks(size_t npix, int C) {
+    const size_t PL = 256 / (C / 4);
+    size_t b = (npix + PL * 16 - 1) / (PL * 16);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// forward (training statistics, or inference with the moving statistics); returns false when the shape is not covered
+bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps) {
+    if (m->desc.dtype != DNNCA_F32 || !bn_fast_ok(o.inA.d) || o.out.d.ps % 4) return false;
+    const int C = o.inA.d.C;
+    const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
+    const double tb = 4.0 * npix * C;
+    if (training) {
+        if (!m->dry) (void)hipMemsetAsync(o.ws, 0, (size_t)2 * C * 8, m->stream);
+        LAUNCH(m, "bn_stats", tb, 3 * tb / 4,
+               hipLaunchKernelGGL(k_bn_stats_fast, dim3(bn_blocks(npix, C)), dim3(256), 0, m->stream, npix, o.inA.d.p, C, o.ws));
+        LAUNCH(m, "bn_finalize", 0, 0,
+               hipLaunchKernelGGL(k_bn_finalize_raw, dim3((C + 255) / 256), dim3(256), 0, m->stream, C, (double)npix, o.ws,
+                                  m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off, m->state + o.mv_off, o.coef, momentum, eps));
+    } else {
+        LAUNCH(m, "g_bn_finalize", 0, 0,
+               g_bn_finalize(m->stream, C, (double)npix, o.ws, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,
+                             m->state + o.mv_off, o.coef, 0, momentum, eps));
+    }
+    const size_t n4 = npix * (C / 4);
+    LAUNCH(m, "bn_apply", 2 * tb, tb / 2,
+           hipLaunchKernelGGL(k_bn_apply_fast, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, m->stream, n4, o.inA.d.p,
+                              o.out.d.p, C, o.out.d.ps, o.coef));
+    return true;
+}
+
+bool fast_bn_bwd(Model* m, int B, Op& o) {
+    if (m->desc.dtype != DNNCA_F32 || !bn_fast_ok(o.inA.d) || o.out.g.ps % 4 || o.inA.g.ps != o.inA.d.C) return false;
+    const int C = o.inA.d.C;
+    const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
+    const double tb = 4.0 * npix * C;
+    LAUNCH(m, "bn_bwd_reduce", 2 * tb, tb,
+           hipLaunchKernelGGL(k_bn_bwd_reduce_fast, dim3(bn_blocks(npix, C)), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C,
+                              o.out.g.ps, o.coef, m->g + o.w_off, m->g + o.b_off));
+    const size_t n4 = npix * (C / 4);
+    LAUNCH(m, "bn_bwd_apply", 3 * tb, 2 * tb,
+           hipLaunchKernelGGL(k_bn_bwd_apply_fast, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, m->stream, n4, o.inA.d.p,
+                              o.out.g.p, o.inA.g.p, C, o.out.g.ps, (int)o.accA, o.coef, m->p + o.w_off, m->g + o.w_off,
+                              m->g + o.b_off, (float)(1.0 / (double)npix)));
+    return true;
+}
+
+}  // namespace dnnca

@@ -386,8 +386,9 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 int C = o.inA.d.C;
                 double n = (double)B * o.inA.d.H * o.inA.d.W;
                 double tb = 4.0 * nelem(B, o.inA.d);
+                if (!generic && fast_bn_fwd(this, B, o, training, kBnMomentum, kBnEps)) break;
                 if (training) {
-                    HIP_TRY(hipMemsetAsync(o.ws, 0, (size_t)2 * C * 8, stream));
+                    if (!dry) HIP_TRY(hipMemsetAsync(o.ws, 0, (size_t)2 * C * 8, stream));
                     LAUNCH(this, "g_bn_stats_mean", tb, tb / 4, g_bn_stats_mean(stream, B, o.inA.d, o.ws));
                     LAUNCH(this, "g_bn_stats_var", tb, tb / 2, g_bn_stats_var(stream, B, o.inA.d, o.ws));
                 }
@@ -406,7 +407,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
             case OP_TCONV: {
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
                 double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
-                if (!generic && fast_tconv_fwd(this, B, o, bytes, flops)) break;
+                if (!generic && (fast_tconv_fwd(this, B, o, bytes, flops) || ig_tconv_fwd(this, B, o, bytes, flops))) break;
                 LAUNCH(this, "g_tconv_fwd", bytes, flops,
                        g_tconv_fwd(stream, B, o.inA.d, p + o.w_off, p + o.b_off, o.out.d, o.k));
                 break;
@@ -485,6 +486,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 case OP_BN: {
                     double tb = 4.0 * nelem(B, o.inA.d);
                     double n = (double)B * o.inA.d.H * o.inA.d.W;
+                    if (!generic && fast_bn_bwd(this, B, o)) break;
                     LAUNCH(this, "g_bn_bwd_reduce", 2 * tb, tb,
                            g_bn_bwd_reduce(stream, B, o.inA.d, o.out.g, o.coef, g + o.w_off, g + o.b_off));
                     LAUNCH(this, "g_bn_bwd_apply", 3 * tb, 2 * tb,
@@ -503,7 +505,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 case OP_TCONV: {
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * nelem(B, o.inA.d);
                     double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
-                    if (!generic && fast_tconv_bwd(this, B, o, ob, ib, flops)) break;
+                    if (!generic && (fast_tconv_bwd(this, B, o, ob, ib, flops) || ig_tconv_bwd(this, B, o, ob, ib, flops))) break;
                     if (o.maskA) { set_error("internal: masked transposed-conv gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     LAUNCH(this, "g_tconv_wgrad", ob + ib, flops,
                            g_tconv_wgrad(stream, B, o.inA.d, o.out.g, g + o.w_off, g + o.b_off, o.k));
