@@ -427,6 +427,218 @@ __global__ __launch_bounds__(256) void k_ig_tconv_wgrad(TcArgs p) {
 
 }  // namespace ig
 
+// ================================================================================================ bf16 variants
+// dtype = DNNCA_BF16 (configs/unet_big.yaml as benchmarked: bf16 contraction, fp32 master weights / activations /
+// accumulation): operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) while they are staged into LDS
+// and the contraction runs on v_mfma_f32_16x16x32_bf16 (16x the f32 MFMA rate).  Tensors in HBM stay fp32.
+namespace igb {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TY = ig::TY, TX = ig::TX, PATCH = ig::PATCH;
+constexpr int CK = 32;                  // K elements per staged chunk = one 16x16x32 MFMA
+constexpr int RS = 40;                  // LDS row stride in bf16 (80 B): conflict-free 16-byte fragment reads
+
+using ig::lds_barrier;
+using ig::ConvArgs;
+
+// per-step bf16 copies of the conv kernels: wf[t][co][ci] = w[t][ci][co] (forward: K = ci contiguous),
+//                                            wd[t][ci][co] = w[8-t][ci][co] (data gradient: K = co contiguous)
+struct PrepDesc {
+    int w_off, cin, cout;
+};
+__global__ void k_igb_prep(const PrepDesc* __restrict__ descs, const float* __restrict__ params, bf16_t* __restrict__ wf,
+                           bf16_t* __restrict__ wd) {
+    const PrepDesc d = descs[blockIdx.y];
+    const int n = 9 * d.cin * d.cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int co = i % d.cout, ci = (i / d.cout) % d.cin, t = i / (d.cin * d.cout);
+        const float v = params[d.w_off + i];
+        wf[d.w_off + ((size_t)t * d.cout + co) * d.cin + ci] = (bf16_t)v;
+        wd[d.w_off + ((size_t)(8 - t) * d.cin + ci) * d.cout + co] = (bf16_t)v;
+    }
+}
+
+// MODE 0 forward, MODE 1 data gradient.  w16: [9][N channels][K channels] bf16 (K contiguous)
+template <int NN, int MODE>
+__global__ __launch_bounds__(256) void k_igb_conv(ConvArgs p, const bf16_t* __restrict__ w16) {
+    constexpr int NT = 16 * NN;
+    __shared__ bf16_t a_lds[PATCH * RS];
+    __shared__ bf16_t b_lds[9 * NT * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
+    const int tile = blockIdx.x, bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = bx * TX, y0 = by * TY;
+    const int co0 = blockIdx.y * NT;
+
+    f32x4 acc[2][NN];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int cc = 0; cc < kin; cc += CK) {
+        const bool second = cc >= p.c_src0;
+        const float* src = second ? p.src[1] : p.src[0];
+        const int cs = second ? p.c_src1 : p.c_src0, c0 = second ? cc - p.c_src0 : cc;
+        lds_barrier();
+        for (int i = tid; i < PATCH * (CK / 4); i += 256) {
+            const int px = i >> 3, c4 = i & 7;
+            const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(src + (((size_t)b * p.H + iy) * p.W + ix) * cs + c0 + 4 * c4);
+            bf16x4 h;
+            h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+            *reinterpret_cast<bf16x4*>(a_lds + px * RS + 4 * c4) = h;
+        }
+        for (int i = tid; i < 9 * NT * 4; i += 256) {
+            const int part = i & 3, r = i >> 2;            // r = tap * NT + n
+            const int tap = r / NT, n = r - tap * NT;
+            const uint4 v = *reinterpret_cast<const uint4*>(w16 + ((size_t)tap * nout + co0 + n) * kin + cc + 8 * part);
+            *reinterpret_cast<uint4*>(b_lds + r * RS + 8 * part) = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            bf16x8 bv[NN];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(b_lds + (tap * NT + 16 * j + m16) * RS + 8 * q);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(a_lds + ((2 * wave + r + dy) * (TX + 2) + m16 + dx) * RS + 8 * q);
+#pragma unroll
+                for (int j = 0; j < NN; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[r][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int y = y0 + 2 * wave + r;
+        if (y >= p.H) continue;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            const int co = co0 + 16 * j + m16;
+            const int which = co >= p.n_dst0;
+            const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co - p.n_dst0 : co;
+            const float bias = (MODE == 0 && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = x0 + 4 * q + i;
+                if (x >= p.W) continue;
+                const size_t o = (((size_t)b * p.H + y) * p.W + x) * cw + cl;
+                float v = acc[r][j][i];
+                if (MODE == 0) {
+                    v += bias;
+                    v = p.alpha < 0.f ? v : (v > 0.f ? v : p.alpha * v);
+                } else {
+                    if (p.acc[which]) v += p.dst[which][o];
+                    if (p.mask[which]) v *= p.mask[which][o] > 0.f ? 1.0f : p.alpha;
+                }
+                p.dst[which][o] = v;
+            }
+        }
+    }
+}
+
+// weight gradient, bf16: M = 16 input channels, N = 16*NN output channels, K = 32 pixels (2 tile rows) per MFMA.
+// Both operands need K = pixels contiguous, i.e. the transposes of the NHWC tiles: they are written transposed into LDS
+// while staging; the input patch is stored three times, shifted by dx = 0,1,2, so that every fragment read is 16-B aligned.
+template <int NN>
+__global__ __launch_bounds__(256) void k_igb_wgrad(ig::WgArgs p) {
+    constexpr int NT = 16 * NN;
+    constexpr int XROW = 16, XCI = (TY + 2) * XROW + 8;      // bf16 strides of xT[dx][ci][row][col]
+    constexpr int GCO = TY * 16 + 8;                         // bf16 stride of gT[co][row][col]
+    __shared__ bf16_t xT[3 * 16 * XCI];
+    __shared__ bf16_t gT[NT * GCO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int c0 = blockIdx.y * 16, co0 = blockIdx.z * NT;
+    const bool do_bias = p.dbias && blockIdx.y == 0;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+
+    f32x4 acc[9][NN], accb[NN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NN; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.psplit) {
+        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+        const int x0 = bx * TX, y0 = by * TY;
+        lds_barrier();
+        for (int i = tid; i < PATCH * 4; i += 256) {
+            const int px = i >> 2, c4 = i & 3;
+            const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.cs + c0 + 4 * c4);
+            const bf16_t h[4] = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int col = lx - dx;
+                if (col < 0 || col >= TX) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xT[(dx * 16 + 4 * c4 + k) * XCI + ly * XROW + col] = h[k];
+            }
+        }
+        for (int i = tid; i < TY * TX * (NT / 4); i += 256) {
+            const int n4 = i % (NT / 4), px = i / (NT / 4);
+            const int ly = px / TX, lx = px - ly * TX;
+            const int iy = y0 + ly, ix = x0 + lx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy < p.H && ix < p.W)
+                v = *reinterpret_cast<const float4*>(p.dz + (((size_t)b * p.H + iy) * p.W + ix) * p.cout + co0 + 4 * n4);
+            gT[(4 * n4 + 0) * GCO + ly * 16 + lx] = (bf16_t)v.x;
+            gT[(4 * n4 + 1) * GCO + ly * 16 + lx] = (bf16_t)v.y;
+            gT[(4 * n4 + 2) * GCO + ly * 16 + lx] = (bf16_t)v.z;
+            gT[(4 * n4 + 3) * GCO + ly * 16 + lx] = (bf16_t)v.w;
+        }
+        lds_barrier();
+        // wave w: K-step = tile rows 2w, 2w+1 (32 pixels); fragment element j of lane quarter q = pixel (row 2w + q/2, col 8(q&1) + j)
+        const int row = 2 * wave + (q >> 1), col = 8 * (q & 1);
+        bf16x8 bv[NN];
+#pragma unroll
+        for (int j = 0; j < NN; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(gT + (16 * j + m16) * GCO + row * 16 + col);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(xT + ((t % 3) * 16 + m16) * XCI + (row + t / 3) * XROW + col);
+#pragma unroll
+            for (int j = 0; j < NN; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[t][j], 0, 0, 0);
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < NN; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bv[j], accb[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(p.dw + ((size_t)t * p.cin_total + p.ci_off + c0 + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
+    if (do_bias && q == 0) {
+#pragma unroll
+        for (int j = 0; j < NN; ++j) atomicAdd(p.dbias + co0 + 16 * j + m16, accb[j][0]);
+    }
+}
+
+}  // namespace igb
+
 // ================================================================================================ host side
 struct IgPlan {
     bool built = false;
@@ -434,6 +646,12 @@ struct IgPlan {
     ig::FlipDesc* flips_dev = nullptr;
     float* flipped = nullptr;        // same layout / offsets as the parameter vector (only conv kernels are filled)
     int max_w = 0;
+    // bf16 mode: per-step bf16 copies of the conv kernels (forward layout / data-gradient layout)
+    std::vector<igb::PrepDesc> preps;
+    igb::PrepDesc* preps_dev = nullptr;
+    igb::bf16_t* wf = nullptr;
+    igb::bf16_t* wd = nullptr;
+    int max_wb = 0;
 };
 static std::map<Model*, IgPlan> g_ig;
 
@@ -442,7 +660,7 @@ void ig_release(Model* m) { g_ig.erase(m); }
 static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
 
 bool ig_conv_supported(const Model* m, const Op& o) {
-    if (o.type != OP_CONV || o.k != 3 || m->desc.dtype != DNNCA_F32) return false;
+    if (o.type != OP_CONV || o.k != 3) return false;
     if (!dense(o.inA.d) || !dense(o.inB.d) || !dense(o.out.d)) return false;
     const int CA = o.inA.d.C, CB = o.inB.d.C, CO = o.out.d.C;
     return CA % 16 == 0 && CB % 16 == 0 && CO % 16 == 0 && CA > 0;
@@ -450,17 +668,35 @@ bool ig_conv_supported(const Model* m, const Op& o) {
 
 static int pick_nn(int cout) { return cout % 64 == 0 ? 4 : (cout % 32 == 0 ? 2 : 1); }
 
+// bf16 contraction: requested by the model description and possible when every K chunk holds 32 channels of one source
+static bool use_bf16(const Model* m, const Op& o) {
+    return m->desc.dtype == DNNCA_BF16 && o.inA.d.C % 32 == 0 && o.inB.d.C % 32 == 0 && o.out.d.C % 32 == 0;
+}
+
 int ig_prepare(Model* m) {
     if (m->desc.flags & 1) return DNNCA_OK;
     IgPlan& pl = g_ig[m];
     if (!pl.built) {
         pl.built = true;
         for (const Op& o : m->ops) {
-            if (!ig_conv_supported(m, o) || !o.need_din) continue;
+            if (!ig_conv_supported(m, o) || !o.need_din || use_bf16(m, o)) continue;
             ig::FlipDesc d{(int)o.w_off, o.inA.d.C + o.inB.d.C, o.out.d.C};
             pl.flips.push_back(d);
             int n = 9 * d.cin * d.cout;
             if (n > pl.max_w) pl.max_w = n;
+        }
+        for (const Op& o : m->ops) {
+            if (!ig_conv_supported(m, o) || !use_bf16(m, o)) continue;
+            igb::PrepDesc d{(int)o.w_off, o.inA.d.C + o.inB.d.C, o.out.d.C};
+            pl.preps.push_back(d);
+            int n = 9 * d.cin * d.cout;
+            if (n > pl.max_wb) pl.max_wb = n;
+        }
+        if (!pl.preps.empty()) {
+            DN_TRY(m->alloc((void**)&pl.preps_dev, pl.preps.size() * sizeof(igb::PrepDesc)));
+            DN_TRY(m->alloc((void**)&pl.wf, (size_t)m->nT * 2 + 16));
+            DN_TRY(m->alloc((void**)&pl.wd, (size_t)m->nT * 2 + 16));
+            HIP_TRY(hipMemcpyAsync(pl.preps_dev, pl.preps.data(), pl.preps.size() * sizeof(igb::PrepDesc), hipMemcpyHostToDevice, m->stream));
         }
         if (!pl.flips.empty()) {
             DN_TRY(m->alloc((void**)&pl.flips_dev, pl.flips.size() * sizeof(ig::FlipDesc)));
@@ -468,6 +704,13 @@ int ig_prepare(Model* m) {
             HIP_TRY(hipMemcpyAsync(pl.flips_dev, pl.flips.data(), pl.flips.size() * sizeof(ig::FlipDesc), hipMemcpyHostToDevice, m->stream));
             HIP_TRY(hipStreamSynchronize(m->stream));
         }
+    }
+    if (!pl.preps.empty()) {
+        int bx = (pl.max_wb + 255) / 256;
+        if (bx > 1024) bx = 1024;
+        LAUNCH(m, "igb_prep", 8.0 * m->nT, 0,
+               hipLaunchKernelGGL(igb::k_igb_prep, dim3(bx, (unsigned)pl.preps.size()), dim3(256), 0, m->stream, pl.preps_dev, m->p,
+                                  pl.wf, pl.wd));
     }
     return DNNCA_OK;
 }
@@ -493,6 +736,15 @@ static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* nam
     else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv<1, MODE>), grid, dim3(256), 0, m->stream, a));
 }
 
+template <int MODE>
+static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, int cout, const char* name, double bytes,
+                       double flops) {
+    const int nn = pick_nn(cout);
+    dim3 grid(a.tiles_x * a.tiles_y * a.B, cout / (16 * nn));
+    if (nn == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv<4, MODE>), grid, dim3(256), 0, m->stream, a, w16));
+    else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv<2, MODE>), grid, dim3(256), 0, m->stream, a, w16));
+}
+
 bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
     if (!ig_conv_supported(m, o)) return false;
     ig::ConvArgs a{};
@@ -505,6 +757,11 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
     a.tiles_x = (a.W + ig::TX - 1) / ig::TX;
     a.tiles_y = (a.H + ig::TY - 1) / ig::TY;
     a.alpha = o.alpha;
+    if (use_bf16(m, o)) {
+        IgPlan& pl = g_ig[m];
+        launch_igb<0>(m, a, pl.wf + o.w_off, o.out.d.C, "igb_conv_fwd", bytes, flops);
+        return true;
+    }
     launch_ig<0>(m, a, o.out.d.C, "ig_conv_fwd", bytes, flops);
     return true;
 }
@@ -539,7 +796,9 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         w.psplit = psplit;
         dim3 grid(psplit, w.cs / ig::CK, CO / (16 * nn));
         const double bb = (out_bytes + in_bytes) / (CB ? 2 : 1), ff = flops / (CB ? 2 : 1);
-        if (nn == 4) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<4>), grid, dim3(256), 0, m->stream, w));
+        if (use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
+        else if (use_bf16(m, o) && nn == 2) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<2>), grid, dim3(256), 0, m->stream, w));
+        else if (nn == 4) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<4>), grid, dim3(256), 0, m->stream, w));
         else if (nn == 2) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<2>), grid, dim3(256), 0, m->stream, w));
         else LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<1>), grid, dim3(256), 0, m->stream, w));
     }
@@ -555,13 +814,16 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
         a.tiles_x = tiles_x; a.tiles_y = tiles_y;
         a.alpha = o.mask_alpha;
-        launch_ig<1>(m, a, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
+        if (use_bf16(m, o))
+            launch_igb<1>(m, a, pl.wd + o.w_off, CA + CB, "igb_conv_dgrad", out_bytes + in_bytes, flops);
+        else
+            launch_ig<1>(m, a, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
     }
     return true;
 }
 
 bool ig_tconv_supported(const Model* m, const Op& o) {
-    if (o.type != OP_TCONV || o.k != 2 || m->desc.dtype != DNNCA_F32) return false;
+    if (o.type != OP_TCONV || o.k != 2) return false;
     if (!dense(o.inA.d) || !dense(o.out.d)) return false;
     return o.inA.d.C % 16 == 0 && o.out.d.C % 16 == 0;
 }

@@ -736,7 +736,7 @@ unsigned long long* fast_debug_stamps(Model* m) { return g_plans[m].stamps; }
 static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
 
 static bool conv_supported(const Model* m, const Op& o) {
-    if (o.type != OP_CONV || o.k != 3 || m->desc.dtype != DNNCA_F32) return false;
+    if (o.type != OP_CONV || o.k != 3) return false;
     if (!dense(o.inA.d) || !dense(o.inB.d) || !dense(o.out.d)) return false;
     const int CA = o.inA.d.C, CB = o.inB.d.C, CO = o.out.d.C;
     if (CB && CB != CA) return false;

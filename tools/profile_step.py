@@ -21,12 +21,13 @@ ap.add_argument('--batch', type=int, default=0)
 ap.add_argument('--size', type=int, default=512)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--generic', action='store_true')
+ap.add_argument('--dtype', default='f32')
 a = ap.parse_args()
 c = CONFIGS[a.config]
 B = a.batch or c['B']
 dev.init_device(0)
 m = dev.DeviceModel(c['arch'], c['C'], a.size, a.size, B, rate=2, kernel_size=3, conv_stride=1, padding='same',
-                    force_generic=a.generic, **c['opts'])
+                    force_generic=a.generic, dtype=a.dtype, **c['opts'])
 m.init_glorot(seed=2)
 x, y = synthetic_batch(B, a.size, a.size, c['C'])
 xb, yb = dev.DeviceBuffer(x), dev.DeviceBuffer(y)
