@@ -23,6 +23,7 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
 bool fast_label_stats(Model* m, size_t n, const float* y);
 bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps);
 bool fast_bn_bwd(Model* m, int B, Op& o);
+bool fast_bn_supported(const Model* m, const Op& o);
 void fast_plan_masks(Model* m);
 // implicit-GEMM MFMA path for channel counts that are multiples of 16 (kernels_igemm.hip)
 bool ig_conv_supported(const Model* m, const Op& o);

@@ -1001,6 +1001,7 @@ void fast_plan_masks(Model* m) {
         else if (c.type == OP_POOL) can = fast_pool_supported(m, c);
         else if (c.type == OP_TCONV) can = fast_tconv_supported(m, c) || ig_tconv_supported(m, c);
         else if (c.type == OP_HEAD) can = fast_head_supported(m, c);
+        else if (c.type == OP_BN) can = fast_bn_supported(m, c);
         if (!can) continue;
         (which ? c.maskB : c.maskA) = true;
         c.mask_alpha = P.alpha;

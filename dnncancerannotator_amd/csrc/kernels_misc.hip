@@ -295,10 +295,10 @@ struct HeadArgs {
     float gscale;
     int mask;              // multiply dfeat by act'(feat)
     float alpha;
-    int n4;                // number of 4-pixel chunks
+    int n4;                // number of PX-pixel chunks (PX = 4 for C = 3, 1 for wide heads)
 };
 
-template <int C>
+template <int C, int PX>
 __global__ __launch_bounds__(256) void k_head_train(HeadArgs p) {
     __shared__ float red[4][C + 2];
     float wv[C];
@@ -318,12 +318,13 @@ __global__ __launch_bounds__(256) void k_head_train(HeadArgs p) {
 #pragma unroll
     for (int c = 0; c < C; ++c) sdw[c] = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < p.n4; i += gridDim.x * 256) {
-        float f[4 * C], z[4], df[4 * C];
+        float f[PX * C], z[PX], df[PX * C];
 #pragma unroll
-        for (int v = 0; v < C; ++v) ld4(f + 4 * v, p.feat + (size_t)i * 4 * C + 4 * v);
-        ld4(z, p.y + (size_t)i * 4);
+        for (int v = 0; v < PX * C / 4; ++v) ld4(f + 4 * v, p.feat + (size_t)i * PX * C + 4 * v);
+        if constexpr (PX == 4) ld4(z, p.y + (size_t)i * 4);
+        else z[0] = p.y[i];
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
+        for (int px = 0; px < PX; ++px) {
             float x = bias;
 #pragma unroll
             for (int c = 0; c < C; ++c) x = fmaf(f[px * C + c], wv[c], x);
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void k_head_train(HeadArgs p) {
             }
         }
 #pragma unroll
-        for (int v = 0; v < C; ++v) st4(p.dfeat + (size_t)i * 4 * C + 4 * v, df + 4 * v);
+        for (int v = 0; v < PX * C / 4; ++v) st4(p.dfeat + (size_t)i * PX * C + 4 * v, df + 4 * v);
     }
     // block reduction: wave shuffles, then 4 partials through LDS, one atomic per value per block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -390,8 +391,9 @@ __global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ p
 }
 
 bool fast_head_supported(const Model* m, const Op& o) {
-    return o.type == OP_HEAD && dense(o.inA.d) && o.inA.d.C == 3 &&
-           ((size_t)o.inA.d.H * o.inA.d.W) % 4 == 0;
+    if (o.type != OP_HEAD || !dense(o.inA.d) || ((size_t)o.inA.d.H * o.inA.d.W) % 4) return false;
+    const int C = o.inA.d.C;
+    return C == 3 || C == 16 || C == 64;      // n_filters_first of configs/{unet,mulmo_unet,unet_big}.yaml
 }
 
 bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cfg& cfg, float gscale, double bytes) {
@@ -411,15 +413,22 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
     a.gscale = gscale;
     a.mask = o.maskA;
     a.alpha = o.mask_alpha;
-    a.n4 = (int)(npix / 4);
+    const int C = o.inA.d.C;
+    a.n4 = (int)(C == 3 ? npix / 4 : npix);
     int blocks = (a.n4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 2048) blocks = 2048;          // partials buffer: 2048 x 72 floats
     a.partials = m->head_partials;
-    LAUNCH(m, "head_train_3", bytes, 30.0 * npix, hipLaunchKernelGGL(k_head_train<3>, dim3(blocks), dim3(256), 0, m->stream, a));
-    LAUNCH(m, "head_reduce", 0, 0,
-           hipLaunchKernelGGL(k_head_reduce<3>, dim3(3 + 2), dim3(256), 0, m->stream, m->head_partials, blocks, a.dw, a.dbias,
-                              m->scalars));
-    return true;
+#define HEAD_CASE(c, px)                                                                                               \
+    if (C == c) {                                                                                                      \
+        LAUNCH(m, "head_train_" #c, bytes, 30.0 * npix, hipLaunchKernelGGL((k_head_train<c, px>), dim3(blocks), dim3(256), 0, m->stream, a)); \
+        LAUNCH(m, "head_reduce", 0, 0,                                                                                 \
+               hipLaunchKernelGGL(k_head_reduce<c>, dim3(c + 2), dim3(256), 0, m->stream, m->head_partials, blocks, a.dw, a.dbias, \
+                                  m->scalars));                                                                        \
+        return true;                                                                                                   \
+    }
+    HEAD_CASE(3, 4) HEAD_CASE(16, 1) HEAD_CASE(64, 1)
+#undef HEAD_CASE
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------ label statistics
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
                                                            float* __restrict__ dx, int C, int dps, int acc,
                                                            const float* __restrict__ coef, const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                           float inv_n) {
+                                                           float inv_n, int mask, float alpha) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int G = C / 4, cq = (int)(i % G);
@@ -620,6 +629,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
     if (acc) {
         const float4 t = *o;
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    if (mask) {      // x is the activated conv output: hand the producing conv its pre-activation gradient directly
+        r.x *= v.x > 0.f ? 1.0f : alpha; r.y *= v.y > 0.f ? 1.0f : alpha;
+        r.z *= v.z > 0.f ? 1.0f : alpha; r.w *= v.w > 0.f ? 1.0f : alpha;
     }
     *o = r;
 }
@@ -657,6 +670,10 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
     return true;
 }
 
+bool fast_bn_supported(const Model* m, const Op& o) {
+    return o.type == OP_BN && bn_fast_ok(o.inA.d) && o.out.d.ps % 4 == 0 && o.out.g.ps % 4 == 0 && o.inA.g.ps == o.inA.d.C;
+}
+
 bool fast_bn_bwd(Model* m, int B, Op& o) {
     if (!bn_fast_ok(o.inA.d) || o.out.g.ps % 4 || o.inA.g.ps != o.inA.d.C) return false;
     const int C = o.inA.d.C;
@@ -669,7 +686,7 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
     LAUNCH(m, "bn_bwd_apply", 3 * tb, 2 * tb,
            hipLaunchKernelGGL(k_bn_bwd_apply_fast, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, m->stream, n4, o.inA.d.p,
                               o.out.g.p, o.inA.g.p, C, o.out.g.ps, (int)o.accA, o.coef, m->p + o.w_off, m->g + o.w_off,
-                              m->g + o.b_off, (float)(1.0 / (double)npix)));
+                              m->g + o.b_off, (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha));
     return true;
 }
 

@@ -333,7 +333,7 @@ int Model::build() {
     DN_TRY(alloc((void**)&dlogits, npix * 4));
     DN_TRY(alloc((void**)&prob, npix * 4));
     DN_TRY(alloc((void**)&thr_dev, 256 * 4));
-    DN_TRY(alloc((void**)&head_partials, 2048 * 8 * 4));
+    DN_TRY(alloc((void**)&head_partials, 2048 * 72 * 4));
     DN_TRY(alloc((void**)&conf_dev, 256 * 4 * 8));
     // Keras defaults for the non-trainable / BN variables: gamma 1, moving_variance 1 (the rest 0)
     {
@@ -487,6 +487,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     double tb = 4.0 * nelem(B, o.inA.d);
                     double n = (double)B * o.inA.d.H * o.inA.d.W;
                     if (!generic && fast_bn_bwd(this, B, o)) break;
+                    if (o.maskA) { set_error("internal: masked batch-norm gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     LAUNCH(this, "g_bn_bwd_reduce", 2 * tb, tb,
                            g_bn_bwd_reduce(stream, B, o.inA.d, o.out.g, o.coef, g + o.w_off, g + o.b_off));
                     LAUNCH(this, "g_bn_bwd_apply", 3 * tb, 2 * tb,
