@@ -6,9 +6,10 @@ from .. import data, dump, engine, load
 
 
 def make_dataset(paths, options, training):
-    """Dataset for `--data_path`.  Supported sources: `synthetic[:HxW[xC]]` (seeded synthetic slices) and `.npz` files
-    holding `x` [N,H,W,C] in [0,1] and `y` [N,H,W].  The reference's image-folder / TFRecord pipeline (data.py:157-207)
-    with its augmentations runs on TensorFlow and is outside the accelerated hot path."""
+    """Dataset for `--data_path`.  Supported sources: the reference's `.tfrecords` exam files (tfrecord.py: centre crop, /255,
+    label split -- no augmentation), `synthetic[:HxW[xC]]` (seeded synthetic slices) and `.npz` files holding `x` [N,H,W,C]
+    in [0,1] and `y` [N,H,W].  The image-folder pipeline and the augmentations (data.py:538-763) run on TensorFlow and are
+    outside the accelerated hot path."""
     batch_size = options.get('batch_size', 8)
     first = paths[0]
     if first.startswith('synthetic'):
@@ -16,11 +17,16 @@ def make_dataset(paths, options, training):
         h, w = (dims + [512, 512])[:2] if len(dims) >= 2 else (512, 512)
         c = dims[2] if len(dims) > 2 else 1
         return data.SyntheticDataset(batch_size, h, w, c, repeat=training, n_batches=4 if training else 2)
+    if all(p.endswith('.tfrecords') for p in paths):          # the reference's exam files (data.py:166-169)
+        from ..tfrecord import TFRecordDataset
+        slice_types = options.get('slice_types', ['TRA', 'ADC', 'DWI', 'DCEE', 'DCEL', 'label'])
+        return TFRecordDataset(paths, slice_types, batch_size, output_size=tuple(options.get('output_size', (512, 512))),
+                               repeat=training, drop_remainder=training)
     if all(p.endswith('.npz') for p in paths):
         import numpy as np
         xs, ys = zip(*((z['x'], z['y']) for z in map(np.load, paths)))
         return data.ArrayDataset(np.concatenate(xs), np.concatenate(ys), batch_size, repeat=training, drop_remainder=training)
-    raise NotImplementedError('data_path %r: supported sources are synthetic[:HxW[xC]] and .npz files' % (paths,))
+    raise NotImplementedError('data_path %r: supported sources are .tfrecords, synthetic[:HxW[xC]] and .npz files' % (paths,))
 
 
 def train(config, save_path, data_path, max_steps, early_stop_steps=None, save_freq=500, validate=False,

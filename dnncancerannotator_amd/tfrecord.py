@@ -1,0 +1,276 @@
+"""Reader (and writer, for tests / synthetic data) of the reference's TFRecord exam files -- without TensorFlow.
+
+Schema (annotator/data.py:238-254 writer, :448-470 reader): uncompressed TFRecord framing (`_TFRECORD_COMPRESSION = None`,
+data.py:59); each record is a `tf.train.Example` with features
+    slices      bytes   tf.io.serialize_tensor(uint8 [N, H, W, C])  = a serialized TensorProto
+    patientID   int64, examID int64, path bytes, category bytes, shape int64[4], slice_types bytes list (C names).
+The element pipeline on top of it mirrors data.py:473-487 (channel selection by slice type), :195-206 (centre crop,
+/255) and :766-788 (`label` channel -> y, the others -> x).
+
+Formats implemented from their public specifications: TFRecord framing (length, masked CRC-32C, data, masked CRC-32C),
+protobuf wire format (varint / 64-bit / length-delimited / 32-bit), tensorflow/core/example/{example,feature}.proto and
+tensorflow/core/framework/{tensor,tensor_shape}.proto field numbers.  No file of the reference ships with the repo."""
+
+import struct
+from collections import namedtuple
+
+import numpy as np
+
+# ------------------------------------------------------------------------------------------------ CRC-32C (Castagnoli)
+_CRC_TABLE = None
+
+
+def _crc_table():
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        poly = 0x82F63B78
+        t = np.zeros(256, np.uint32)
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ poly if c & 1 else c >> 1
+            t[i] = c
+        _CRC_TABLE = t
+    return _CRC_TABLE
+
+
+def crc32c(data):
+    t = _crc_table()
+    c = 0xFFFFFFFF
+    for b in bytes(data):
+        c = int(t[(c ^ b) & 0xFF]) ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def masked_crc(data):
+    c = crc32c(data)
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------ TFRecord framing
+def read_records(path, verify_payload_crc=False):
+    """Yields the payload of every record.  The 12-byte header CRC is always checked; the payload CRC (a pure-Python
+    loop over megabytes of pixels) only on request."""
+    with open(path, 'rb') as f:
+        while True:
+            header = f.read(12)
+            if not header:
+                return
+            if len(header) < 12:
+                raise IOError('truncated TFRecord header in %s' % path)
+            length, = struct.unpack('<Q', header[:8])
+            if struct.unpack('<I', header[8:])[0] != masked_crc(header[:8]):
+                raise IOError('corrupt TFRecord length CRC in %s' % path)
+            data = f.read(length)
+            footer = f.read(4)
+            if len(data) < length or len(footer) < 4:
+                raise IOError('truncated TFRecord payload in %s' % path)
+            if verify_payload_crc and struct.unpack('<I', footer)[0] != masked_crc(data):
+                raise IOError('corrupt TFRecord payload CRC in %s' % path)
+            yield data
+
+
+def write_records(path, payloads):
+    with open(path, 'wb') as f:
+        for data in payloads:
+            head = struct.pack('<Q', len(data))
+            f.write(head + struct.pack('<I', masked_crc(head)) + data + struct.pack('<I', masked_crc(data)))
+
+
+# ------------------------------------------------------------------------------------------------ protobuf wire format
+def _varint(buf, pos):
+    result, shift = 0, 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        result |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return result, pos
+        shift += 7
+
+
+def _fields(buf):
+    """Yields (field number, wire type, value) of one message; length-delimited values are memoryviews."""
+    buf = memoryview(buf)
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _varint(buf, pos)
+        num, wt = key >> 3, key & 7
+        if wt == 0:
+            val, pos = _varint(buf, pos)
+        elif wt == 1:
+            val, pos = bytes(buf[pos:pos + 8]), pos + 8
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            val, pos = buf[pos:pos + ln], pos + ln
+        elif wt == 5:
+            val, pos = bytes(buf[pos:pos + 4]), pos + 4
+        else:
+            raise ValueError('unsupported protobuf wire type %d' % wt)
+        yield num, wt, val
+
+
+def _enc_varint(v):
+    out = bytearray()
+    v &= (1 << 64) - 1
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _enc_field(num, wt, payload):
+    if wt == 2:
+        return _enc_varint((num << 3) | 2) + _enc_varint(len(payload)) + bytes(payload)
+    return _enc_varint((num << 3) | wt) + bytes(payload)
+
+
+# ------------------------------------------------------------------------------------------------ Example / TensorProto
+def parse_example(data):
+    """tf.train.Example -> {name: list of bytes | list of int | list of float}."""
+    out = {}
+    for num, _, features in _fields(data):
+        if num != 1:
+            continue
+        for fnum, _, entry in _fields(features):           # map<string, Feature> entries
+            if fnum != 1:
+                continue
+            key, feature = None, None
+            for enum, _, v in _fields(entry):
+                if enum == 1:
+                    key = bytes(v).decode()
+                elif enum == 2:
+                    feature = v
+            values = []
+            for knum, _, lst in _fields(feature if feature is not None else b''):
+                for vnum, vwt, v in _fields(lst):
+                    if vnum != 1:
+                        continue
+                    if knum == 1:                           # BytesList
+                        values.append(bytes(v))
+                    elif knum == 3:                         # Int64List (packed or not)
+                        if vwt == 2:
+                            pos, raw = 0, bytes(v)
+                            while pos < len(raw):
+                                x, pos = _varint(raw, pos)
+                                values.append(x - (1 << 64) if x >= 1 << 63 else x)
+                        else:
+                            values.append(v - (1 << 64) if v >= 1 << 63 else v)
+                    elif knum == 2:                         # FloatList
+                        raw = bytes(v)
+                        values.extend(struct.unpack('<%df' % (len(raw) // 4), raw))
+            out[key] = values
+    return out
+
+
+DT_UINT8 = 4
+
+
+def parse_tensor_uint8(data):
+    """tf.io.parse_tensor(x, tf.uint8) for what tf.io.serialize_tensor wrote: dtype 1, tensor_shape 2, tensor_content 4."""
+    dtype, dims, content = None, [], None
+    for num, _, v in _fields(data):
+        if num == 1:
+            dtype = v
+        elif num == 2:
+            for snum, _, dim in _fields(v):
+                if snum == 2:
+                    for dnum, _, size in _fields(dim):
+                        if dnum == 1:
+                            dims.append(size)
+        elif num == 4:
+            content = v
+    if dtype != DT_UINT8:
+        raise ValueError('expected a uint8 tensor (dtype %d), got dtype %s' % (DT_UINT8, dtype))
+    return np.frombuffer(content, np.uint8).reshape(dims)
+
+
+def serialize_tensor_uint8(a):
+    a = np.ascontiguousarray(a, np.uint8)
+    shape = b''.join(_enc_field(2, 2, _enc_field(1, 0, _enc_varint(d))) for d in a.shape)
+    return _enc_field(1, 0, _enc_varint(DT_UINT8)) + _enc_field(2, 2, shape) + _enc_field(4, 2, a.tobytes())
+
+
+def make_example(slices, patient_id, exam_id, path, category, slice_types):
+    """The record annotator/data.py:238-254 writes for one exam (slices uint8 [N, H, W, C])."""
+    def bytes_list(vals):
+        return _enc_field(1, 2, b''.join(_enc_field(1, 2, v) for v in vals))
+
+    def int64_list(vals):
+        return _enc_field(3, 2, _enc_field(1, 2, b''.join(_enc_varint(int(v)) for v in vals)))
+
+    feats = {
+        'slices': bytes_list([serialize_tensor_uint8(slices)]),
+        'patientID': int64_list([patient_id]),
+        'examID': int64_list([exam_id]),
+        'path': bytes_list([path.encode()]),
+        'category': bytes_list([category.encode()]),
+        'shape': int64_list(slices.shape),
+        'slice_types': bytes_list([s.encode() for s in slice_types]),
+    }
+    entries = b''.join(_enc_field(1, 2, _enc_field(1, 2, k.encode()) + _enc_field(2, 2, v)) for k, v in feats.items())
+    return _enc_field(1, 2, entries)
+
+
+# ------------------------------------------------------------------------------------------------ dataset
+Exam = namedtuple('Exam', ['slices', 'patientID', 'examID', 'path', 'category', 'slice_types'])
+Spec = namedtuple('Spec', ['shape', 'dtype'])
+
+
+def read_exams(path, output_slice_types=None):
+    """extract_slices_from_tfrecord (data.py:438-512) up to the per-exam level: selects / orders the channels named in
+    `output_slice_types` (data.py:473-487)."""
+    for data in read_records(path):
+        ex = parse_example(data)
+        shape = ex['shape']
+        slices = parse_tensor_uint8(ex['slices'][0]).reshape(shape)
+        types = [t.decode() for t in ex['slice_types']]
+        if output_slice_types is not None:
+            idx = [types.index(t) for t in output_slice_types]
+            slices, types = slices[..., idx], list(output_slice_types)
+        yield Exam(slices, ex['patientID'][0], ex['examID'][0], ex['path'][0].decode(), ex['category'][0].decode(), types)
+
+
+class TFRecordDataset:
+    """Batches (x float32 [B, H, W, C] in [0, 1], y float32 [B, H, W]) from the reference's .tfrecords exam files:
+    centre crop to `output_size` (data.py:195-200), /255 (data.py:205-206), `label` channel -> y, the remaining channels ->
+    x in `slice_types` order (data.py:766-788).  Augmentations (data.py:538-763) are TensorFlow-side and not reproduced."""
+
+    def __init__(self, paths, slice_types, batch_size, output_size=(512, 512), repeat=False, drop_remainder=False, **ignored):
+        self.paths = list(paths)
+        self.slice_types = list(slice_types)
+        assert 'label' in self.slice_types, 'slice_types must name the label channel (data.py:771)'
+        self.batch_size, self.output_size = int(batch_size), tuple(output_size)
+        self.repeat, self.drop_remainder = repeat, drop_remainder
+        self.feature_idx = [i for i, t in enumerate(self.slice_types) if t != 'label']
+        self.label_idx = self.slice_types.index('label')
+        self.element_spec = (Spec((self.batch_size,) + self.output_size + (len(self.feature_idx),), np.float32),
+                             Spec((self.batch_size,) + self.output_size, np.float32))
+
+    def _slices(self):
+        oh, ow = self.output_size
+        for path in self.paths:
+            for exam in read_exams(path, self.slice_types):
+                s = exam.slices
+                gy, gx = (s.shape[1] - oh) // 2, (s.shape[2] - ow) // 2
+                s = s[:, gy:gy + oh, gx:gx + ow, :].astype(np.float32) / np.float32(255.0)
+                for k in range(len(s)):
+                    yield s[k][..., self.feature_idx], s[k][..., self.label_idx]
+
+    def __iter__(self):
+        while True:
+            xs, ys = [], []
+            for x, y in self._slices():
+                xs.append(x)
+                ys.append(y)
+                if len(xs) == self.batch_size:
+                    yield np.stack(xs), np.stack(ys)
+                    xs, ys = [], []
+            if xs and not self.drop_remainder:
+                yield np.stack(xs), np.stack(ys)
+            if not self.repeat:
+                return

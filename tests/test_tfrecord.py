@@ -1,0 +1,121 @@
+"""CPU: the TensorFlow-free TFRecord reader against known answers and an independent protobuf implementation
+(google.protobuf with the published tf.train.Example / TensorProto field numbers declared on the fly)."""
+
+import struct
+
+import numpy as np
+import pytest
+
+from dnncancerannotator_amd import tfrecord as T
+
+
+def test_crc32c_known_answers():
+    assert T.crc32c(b'123456789') == 0xE3069283          # the standard CRC-32C check value
+    assert T.crc32c(b'') == 0
+    assert T.crc32c(bytes(32)) == 0x8A9136AA             # RFC 3720 B.4: 32 bytes of zeros
+    assert T.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43    # RFC 3720 B.4: 32 bytes of ones
+    # TFRecord mask: rotate right by 15, add 0xa282ead8
+    c = T.crc32c(b'abc')
+    assert T.masked_crc(b'abc') == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _pb_messages():
+    """tf.train.Example & friends + the TensorProto subset, declared with google.protobuf (independent of tfrecord.py)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name='dnnca_test_example.proto', package='dt', syntax='proto3')
+
+    def msg(name, fields):
+        m = fd.message_type.add(name=name)
+        for fname, num, ftype, label, tname in fields:
+            f = m.field.add(name=fname, number=num, type=ftype, label=label)
+            if tname:
+                f.type_name = '.dt.' + tname
+        return m
+
+    OPT, REP = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    msg('BytesList', [('value', 1, F.TYPE_BYTES, REP, None)])
+    msg('FloatList', [('value', 1, F.TYPE_FLOAT, REP, None)])
+    msg('Int64List', [('value', 1, F.TYPE_INT64, REP, None)])
+    msg('Feature', [('bytes_list', 1, F.TYPE_MESSAGE, OPT, 'BytesList'), ('float_list', 2, F.TYPE_MESSAGE, OPT, 'FloatList'),
+                    ('int64_list', 3, F.TYPE_MESSAGE, OPT, 'Int64List')])
+    msg('FeatureEntry', [('key', 1, F.TYPE_STRING, OPT, None), ('value', 2, F.TYPE_MESSAGE, OPT, 'Feature')])
+    msg('Features', [('feature', 1, F.TYPE_MESSAGE, REP, 'FeatureEntry')])       # a map is a repeated entry on the wire
+    msg('Example', [('features', 1, F.TYPE_MESSAGE, OPT, 'Features')])
+    msg('Dim', [('size', 1, F.TYPE_INT64, OPT, None)])
+    msg('TensorShapeProto', [('dim', 2, F.TYPE_MESSAGE, REP, 'Dim')])
+    msg('TensorProto', [('dtype', 1, F.TYPE_INT32, OPT, None), ('tensor_shape', 2, F.TYPE_MESSAGE, OPT, 'TensorShapeProto'),
+                        ('tensor_content', 4, F.TYPE_BYTES, OPT, None)])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName('dt.' + n))   # noqa: E731
+    return get
+
+
+def test_example_wire_format_against_google_protobuf():
+    get = pytest.importorskip('google.protobuf') and _pb_messages()
+    rng = np.random.default_rng(0)
+    slices = rng.integers(0, 256, (3, 8, 10, 4), dtype=np.uint8)
+    types = ['TRA', 'ADC', 'DWI', 'label']
+    # (1) what google.protobuf serialises, tfrecord.py parses
+    tp = get('TensorProto')(dtype=4, tensor_content=slices.tobytes())
+    for d in slices.shape:
+        tp.tensor_shape.dim.add(size=d)
+    ex = get('Example')()
+
+    def add(key):
+        e = ex.features.feature.add(key=key)
+        return e.value
+    add('slices').bytes_list.value.append(tp.SerializeToString())
+    add('patientID').int64_list.value.append(1234567890123)
+    add('examID').int64_list.value.append(-7)                  # negative int64: 10-byte varint
+    add('path').bytes_list.value.append(b'/data/cancer/12/3')
+    add('category').bytes_list.value.append(b'cancer')
+    add('shape').int64_list.value.extend(slices.shape)
+    add('slice_types').bytes_list.value.extend(t.encode() for t in types)
+    parsed = T.parse_example(ex.SerializeToString())
+    assert parsed['patientID'] == [1234567890123] and parsed['examID'] == [-7]
+    assert parsed['shape'] == list(slices.shape) and parsed['slice_types'] == [t.encode() for t in types]
+    assert np.array_equal(T.parse_tensor_uint8(parsed['slices'][0]), slices)
+    # (2) what tfrecord.py serialises, google.protobuf parses
+    mine = T.make_example(slices, 42, 7, '/p', 'healthy', types)
+    back = get('Example').FromString(mine)
+    feats = {e.key: e.value for e in back.features.feature}
+    assert list(feats['shape'].int64_list.value) == list(slices.shape)
+    assert list(feats['slice_types'].bytes_list.value) == [t.encode() for t in types]
+    t2 = get('TensorProto').FromString(feats['slices'].bytes_list.value[0])
+    assert t2.dtype == 4 and [d.size for d in t2.tensor_shape.dim] == list(slices.shape) and t2.tensor_content == slices.tobytes()
+
+
+def test_tfrecord_dataset_element_contract(tmp_path):
+    rng = np.random.default_rng(1)
+    types = ['TRA', 'ADC', 'DWI', 'DCEE', 'DCEL', 'label']            # data_options.yaml:7
+    exams = [rng.integers(0, 256, (n, 20, 24, 6), dtype=np.uint8) for n in (3, 2)]
+    for e in exams:
+        e[..., 5] = (e[..., 5] > 200) * 255                            # binary label channel
+    path = str(tmp_path / 'exams.tfrecords')
+    T.write_records(path, [T.make_example(e, 10 + i, i, '/x/%d' % i, 'cancer', types) for i, e in enumerate(exams)])
+    # framing: length, masked crc, payload, masked crc
+    raw = open(path, 'rb').read()
+    n0, = struct.unpack('<Q', raw[:8])
+    assert struct.unpack('<I', raw[8:12])[0] == T.masked_crc(raw[:8])
+    assert struct.unpack('<I', raw[12 + n0:16 + n0])[0] == T.masked_crc(raw[12:12 + n0])
+    assert len(list(T.read_records(path, verify_payload_crc=True))) == 2
+    # channel selection in the requested order (slice_type_tra_dwi_adc.yaml:1), centre crop, /255, label split
+    want = ['TRA', 'DWI', 'ADC', 'label']
+    ds = T.TFRecordDataset([path], want, batch_size=2, output_size=(16, 16))
+    batches = list(ds)
+    assert [len(b[0]) for b in batches] == [2, 2, 1] and ds.element_spec[0].shape == (2, 16, 16, 3)
+    x, y = batches[0]
+    assert x.dtype == np.float32 and y.dtype == np.float32 and x.shape == (2, 16, 16, 3) and y.shape == (2, 16, 16)
+    crop = exams[0][:2, 2:18, 4:20, :]
+    assert np.array_equal(x, crop[..., [0, 2, 1]].astype(np.float32) / np.float32(255.0))
+    assert np.array_equal(y, crop[..., 5].astype(np.float32) / np.float32(255.0)) and set(np.unique(y)) <= {0.0, 1.0}
+    # corruption is detected
+    bad = bytearray(raw)
+    bad[3] ^= 0x01
+    (tmp_path / 'bad.tfrecords').write_bytes(bytes(bad))
+    with pytest.raises(IOError):
+        list(T.read_records(str(tmp_path / 'bad.tfrecords')))
+    meta = list(T.read_exams(path))
+    assert meta[1].patientID == 11 and meta[1].category == 'cancer' and meta[1].slice_types == types
