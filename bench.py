@@ -30,6 +30,14 @@ H = W = 512
 C = 1
 BATCH_PER_GPU = 8              # configs[1]: configs/unet.yaml, batch 8 512x512x1, fp32, 1 x MI355X
 UNET_YAML = dict(n_filters_first=3, n_downsample=3, rate=2, kernel_size=3, conv_stride=1, bn=False, padding='same')
+# the other single-GPU configurations of BASELINE.json (parity-test cases; `--workload` times them for DESIGN.md)
+WORKLOADS = {
+    'unet': dict(arch='unet', C=1, batch=8, dtype='f32', opts=UNET_YAML, name='configs/unet.yaml'),
+    'unet_big': dict(arch='unet', C=1, batch=4, dtype='bf16', name='configs/unet_big.yaml',
+                     opts=dict(n_filters_first=64, n_downsample=4, rate=2, kernel_size=3, conv_stride=1, bn=True, padding='same')),
+    'mulmo_unet': dict(arch='mulmo', C=3, batch=8, dtype='f32', name='configs/mulmo_unet.yaml',
+                       opts=dict(n_filters_first=16, n_downsample=4, rate=2, kernel_size=3, conv_stride=1, bn=True, padding='same')),
+}
 
 
 def rendezvous(rank, world):
@@ -90,6 +98,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--generic', action='store_true', help='force the untuned generic kernels')
+    ap.add_argument('--workload', default='unet', choices=sorted(WORKLOADS), help='default: the metric\'s configuration (unet)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -99,7 +108,10 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
     dev.init_device(local_rank)
-    model = dev.DeviceModel('unet', C, H, W, BATCH_PER_GPU, force_generic=args.generic, **UNET_YAML)
+    wl = WORKLOADS[args.workload]
+    global C, BATCH_PER_GPU
+    C, BATCH_PER_GPU = wl['C'], wl['batch']
+    model = dev.DeviceModel(wl['arch'], C, H, W, BATCH_PER_GPU, force_generic=args.generic, dtype=wl['dtype'], **wl['opts'])
     model.init_glorot(seed=2)          # same weights on every rank (random-init weights of the named architecture)
     uid = rendezvous(rank, world)
     model.comm_init(rank, world, uid)
@@ -150,29 +162,35 @@ def main():
         value = world * BATCH_PER_GPU * args.steps / elapsed
         name, launches, total_ms, bytes_per, flops_per = prof[dominant]
         avg_ms = total_ms / max(launches, 1)
-        achieved = bytes_per / (avg_ms * 1e-3) / 1e9
+        if args.workload == 'unet':          # HBM-bound (AI ~ 9 FLOP/B): algorithmic bytes of the launch / its duration
+            bound, unit, peak = 'hbm', 'GB/s', HBM_PEAK_GBS
+            achieved = bytes_per / (avg_ms * 1e-3) / 1e9
+        else:                                 # dense contractions: algorithmic FLOPs / duration against the MFMA peak
+            bound, unit = 'mfma', 'TFLOP/s'
+            peak = 2500.0 if wl['dtype'] == 'bf16' else 157.3        # MI355X_MICROARCH.md:42-43 (dense)
+            achieved = flops_per / (avg_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == 'unet':
             with open(tpath) as f:
                 traffic = json.load(f).get(dominant)
         line = {
-            'metric': 'MRI slices/sec (fwd+bwd) unet 512x512 bs=8', 'value': round(value, 2), 'unit': 'slices/s',
+            'metric': 'MRI slices/sec (fwd+bwd) %s 512x512 bs=%d' % (args.workload, BATCH_PER_GPU), 'value': round(value, 2), 'unit': 'slices/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs/unet.yaml train step (fwd + weighted BCE + bwd + Adam), batch %d x 512x512x1 '
-                                   'per GPU, fp32, random-init weights' % BATCH_PER_GPU,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
+            'config': {'workload': '%s train step (fwd + weighted BCE + bwd + Adam), batch %d x 512x512x%d '
+                                   'per GPU, %s, random-init weights' % (wl['name'], BATCH_PER_GPU, C, wl['dtype']),
                        'global_batch': world * BATCH_PER_GPU, 'parallelism': 'dp%d' % world,
                        'kernels': 'generic' if args.generic else 'tuned'},
-            'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+            'roofline': {'bound': bound, 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': peak,
+                         'unit': unit, 'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'launches': int(launches), 'avg_launch_us': round(avg_ms * 1e3, 2),
                          'algorithmic_bytes_per_launch': bytes_per,
                          'share_of_step': round(total_ms / (ev_ms if ev_ms > 0 else 1e9), 4)},
             'hip_event_ms_per_step': round(ev_ms / args.steps, 4),
             'final_loss': round(float(out.loss), 6),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'unet':
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1 and rank == 0:
