@@ -226,3 +226,51 @@ def test_unet_big_bf16_contraction_against_oracle(gpu):
     g, gref = m.get_grads().astype(np.float64), O.flatten(spec, grads)
     assert np.isfinite(g).all() and float(np.dot(g, gref) / (np.linalg.norm(g) * np.linalg.norm(gref))) > 0.85
     m.close()
+
+
+def test_cli_train_then_evaluate_on_tfrecords(gpu, tmp_path):
+    """`python3 -m annotator train|evaluate` with the reference's YAML surface and .tfrecords exam files, in a child
+    process (the documented drop-in invocation)."""
+    import subprocess
+    import sys
+    import yaml
+    from dnncancerannotator_amd import tfrecord as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(5)
+    types = ['TRA', 'ADC', 'DWI', 'label']
+    exams = []
+    for i in range(2):
+        s = rng.integers(0, 256, (4, 40, 40, 4), dtype=np.uint8)
+        s[..., 3] = 0
+        s[:, 10:20, 12:22, 3] = 255
+        exams.append(T.make_example(s, i, i, '/e/%d' % i, 'cancer', types))
+    rec = str(tmp_path / 'exams.tfrecords')
+    T.write_records(rec, exams)
+    cfgs = {
+        'unet.yaml': dict(model='UNetAnnotator', model_options=dict(n_filters_first=3, n_downsample=3, rate=2, kernel_size=3,
+                                                                     conv_stride=1, bn=False, padding='same')),
+        'deploy.yaml': {'deploy_options': {'optimizer': 'adam',
+                                           'LearningRateScheduler': 'lambda epoch, current_lr: 0.001 * 0.96 ** (epoch // 1000)',
+                                           'loss': {'class_name': 'WeightedCrossentropy', 'config': {'weight_mul': 3.0}},
+                                           'enable_multigpu': False}},
+        'data.yaml': {'data_options': {'train': {'batch_size': 4, 'output_size': [32, 32], 'slice_types': types},
+                                       'eval': {'batch_size': 8, 'output_size': [32, 32], 'slice_types': types}}},
+    }
+    paths = []
+    for name, obj in cfgs.items():
+        p = tmp_path / name
+        p.write_text(yaml.safe_dump(obj))
+        paths.append(str(p))
+    save = str(tmp_path / 'run')
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, '-m', 'annotator', 'train', '--config'] + paths +
+                       ['--save_path', save, '--data_path', rec, '--max_steps', '12', '--save_freq', '6'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert sorted(f for f in os.listdir(os.path.join(save, 'checkpoints')) if f.endswith('.index')) == ['ckpt-12.index', 'ckpt-6.index']
+    assert os.path.exists(os.path.join(save, 'options.yaml')) and os.path.exists(os.path.join(save, 'results.pkl'))
+    r = subprocess.run([sys.executable, '-m', 'annotator', 'evaluate', '--save_path', save, '--data_path', rec, '--tag', 'val',
+                        '--export_csv', '--skip_visualization'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = open(os.path.join(save, 'tfevents', 'val', 'results.csv')).read().strip().splitlines()
+    assert rows[0].startswith('step,loss') and [l.split(',')[0] for l in rows[1:]] == ['6', '12']
