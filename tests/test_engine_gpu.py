@@ -274,3 +274,34 @@ def test_cli_train_then_evaluate_on_tfrecords(gpu, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     rows = open(os.path.join(save, 'tfevents', 'val', 'results.csv')).read().strip().splitlines()
     assert rows[0].startswith('step,loss') and [l.split(',')[0] for l in rows[1:]] == ['6', '12']
+
+
+@pytest.mark.parametrize('arch, C, opts', [
+    ('unet', 1, dict(n_filters_first=3, n_downsample=3, bn=False)),                      # configs/unet.yaml + overlays
+    ('mulmo', 2, dict(n_filters_first=16, n_downsample=2, bn=True)),                      # dense-channel kernels
+])
+def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
+    """Tuned kernels on a non-square image (48 x 80: partial tiles in both directions) with the LeakyReLU and L2-regulariser
+    overlays of the reference (configs/additionals/leakyReLU.yaml, kernel_regularizer.yaml) against the float64 oracle."""
+    full = dict(rate=2, kernel_size=3, conv_stride=1, padding='same',
+                activation={'class_name': 'LeakyReLU', 'config': {'alpha': 0.3}},
+                kernel_regularizer={'class_name': 'L2', 'config': {'l2': 0.01}}, **opts)
+    spec = O.ModelSpec(arch, C, **full)
+    params = Hp.perturbed_params(spec, np.float64)
+    B, H, W = 3, 48, 80
+    rng = np.random.default_rng(11)
+    x = rng.random((B, H, W, C)).astype(np.float32)
+    y = (rng.random((B, H, W)) < 0.05).astype(np.float32)
+    cfg = dict(weight_mul=3.0, weight_add=0.25)
+    loss, grads, logits, state = O.loss_and_grads(spec, params, x.astype(np.float64), y, cfg, training=True)
+    dev_opts = {k: v for k, v in full.items() if k not in ('activation', 'kernel_regularizer')}
+    m = gpu.DeviceModel(arch, C, H, W, B, leaky_alpha=0.3, l2=0.01, **dev_opts)
+    m.set_params(O.flatten(spec, params))
+    if m.n_state:
+        m.set_state(O.flatten(spec, params, trainable=False))
+    out = m.train_step(x, y, 0.0, m.loss_cfg(**cfg))
+    assert abs(out.loss - loss) <= 1e-4 * max(1.0, abs(loss))
+    assert Hp.rel_err(m.get_grads(), O.flatten(spec, grads)) <= 2e-3
+    plan = set(r[0] for r in m.plan())
+    assert any(k.startswith('pgbwd_') or k.startswith('ig_') for k in plan)              # the tuned kernels are the ones planned
+    m.close()
