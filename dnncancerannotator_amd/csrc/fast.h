@@ -9,7 +9,9 @@ int fast_prepare(Model* m);     // per-step operand preparation (weights -> MFMA
 int fast_finish_backward(Model* m);   // folds the weight-gradient slabs into the flat gradient vector
 void fast_release(Model* m);
 unsigned long long* fast_debug_stamps(Model* m);   // tuning aid: in-kernel s_memtime stamps (DNNCA_STAMPS)    // drop the per-model plan
-bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops);
+// `pool`: a max-pool op fused into the conv's epilogue (fast_pool_fusable), or nullptr
+bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool);
+bool fast_pool_fusable(const Model* m, const Op& conv, const Op& pool);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 bool fast_pool_fwd(Model* m, int B, Op& o, double bytes);
 bool fast_pool_bwd(Model* m, int B, Op& o, double bytes);

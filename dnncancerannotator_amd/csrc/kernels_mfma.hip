@@ -102,6 +102,7 @@ struct FwdArgs {
     const float* bmat;       // prepared B operand: [KS][64]
     const float* bias;       // CO floats
     float* dst;              // dense NHWC, CO channels
+    float* pool_dst;         // fused MaxPool2D([2,2], 2) of the output (components.py:54): [B, H/2, W/2, CO] or nullptr
     int B, H, W;
     int tiles_x, tiles_y;
     float alpha;             // activation slope (<0: none)
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
     constexpr int WR = (G + 2) * C, SR = (WR + 3) / 4, KS = NSRC * 3 * SR, LS = T::LS;
     // DB: two stage buffers -> the next tile is committed while other waves still read the current one, one barrier per tile
     constexpr int STAGE4 = NSRC * T::N4, NBUF = DB ? 2 : 1;
-    __shared__ float4 lds4[NBUF * STAGE4 + NW * 48];   // staged tiles + one 16x12 output row per wave
-    float* orow = reinterpret_cast<float*>(lds4 + NBUF * STAGE4) + (threadIdx.x >> 6) * 192;
+    __shared__ float4 lds4[NBUF * STAGE4 + NW * 96];   // staged tiles + two 16x12 output rows per wave
+    float* orow = reinterpret_cast<float*>(lds4 + NBUF * STAGE4) + (threadIdx.x >> 6) * 384;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4, n = m;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) okm = tile_issue<C, TW, NT>(pre[s], mp, p.src[s], nb, nx0, ny0, p.B, p.H, p.W);
         }
-        // every wave owns NCH = 4 M-tiles (same column block tx, rows ty0 + 2i) and interleaves their MFMA chains:
+        // every wave owns NCH M-tiles (same column block tx, adjacent rows NCH*ty0 + i) and interleaves their MFMA chains:
         // independent accumulators keep the matrix pipe issuing back to back (a dependent 16x16x4 f32 chain stalls
         // 8 of every 40 cycles) and put all 60 LDS reads in flight at once
         {
@@ -193,30 +194,48 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
                     for (int k = 0; k < SR; ++k)
 #pragma unroll
                         for (int i = 0; i < NCH; ++i) {
-                            const int ty = ty0 + (NW / TX) * i;
+                            const int ty = NCH * ty0 + i;
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                 lds[s * (T::N4 * 4) + (ty + dy) * LS + aoff + 4 * k], breg[(s * 3 + dy) * SR + k], acc[i], 0, 0, 0);
                         }
             // D[group 4q+r][n] -> the M-tile's output row is 16 groups x 12 contiguous floats: transpose through LDS
             // (same wave writes and reads; DS operations of one wave execute in order) and store 16 B per lane
+            static_assert(NCH == 2, "the fused 2x2 max-pool needs each wave to own a pair of adjacent rows");
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                const int y = y0 + ty0 + (NW / TX) * i;
+                const int y = y0 + NCH * ty0 + i;
+                float* orw = orow + i * 192;
                 if (n < N) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[i][r] + bias;
-                        orow[(4 * q + r) * 12 + n] = p.alpha < 0.f ? v : (v > 0.f ? v : p.alpha * v);
+                        orw[(4 * q + r) * 12 + n] = p.alpha < 0.f ? v : (v > 0.f ? v : p.alpha * v);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int f0 = (x0 + tx * 16 * G) * CO + 4 * lane;          // float index within the image row
                 if (lane < 48 && f0 < p.W * CO && y < p.H) {
-                    const float4 v = reinterpret_cast<const float4*>(orow)[lane];
+                    const float4 v = reinterpret_cast<const float4*>(orw)[lane];
                     *reinterpret_cast<float4*>(p.dst + ((size_t)b * p.H + y) * p.W * CO + f0) = v;
                 }
-                __builtin_amdgcn_wave_barrier();
             }
+            __builtin_amdgcn_wave_barrier();
+            if (p.pool_dst) {
+                // both rows of the pair are in LDS: pooled row = max over the 2x2 windows, 8G pixels x CO = 96 floats
+                const int yp = (y0 >> 1) + ty0, Wp = p.W >> 1;
+                const int fp0 = ((x0 + tx * 16 * G) >> 1) * CO + 4 * lane;   // float index within the pooled row
+                if (lane < 24 && fp0 < Wp * CO && 2 * yp + 1 < p.H) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = 4 * lane + e, pp = f / CO, c = f - pp * CO;
+                        const int i0 = (2 * pp) * CO + c;
+                        o[e] = fmaxf(fmaxf(orow[i0], orow[i0 + CO]), fmaxf(orow[192 + i0], orow[192 + i0 + CO]));
+                    }
+                    *reinterpret_cast<float4*>(p.pool_dst + ((size_t)b * (p.H >> 1) + yp) * Wp * CO + fp0) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         if (DB) {
             if (next < ntiles) {
@@ -749,6 +768,12 @@ static bool conv_supported(const Model* m, const Op& o) {
     return (CA == 3 && CO == 3) || (CA == 6 && CO == 6) || (CA == 12 && CO == 12);
 }
 
+// a MaxPool2D([2,2], 2) that directly consumes this conv's output can ride in the conv's epilogue
+bool fast_pool_fusable(const Model* m, const Op& conv, const Op& pool) {
+    return conv_supported(m, conv) && pool.type == OP_POOL && pool.k == 2 && pool.inA.d.p == conv.out.d.p && dense(pool.out.d) &&
+           conv.out.d.H % 2 == 0 && conv.out.d.W % 2 == 0 && ((conv.out.d.W / 2) * conv.out.d.C) % 4 == 0;
+}
+
 static int build_plan(Model* m, PgPlan& pl) {
     int off = 0;
     auto add = [&](const Op* op, int kind, PrepDesc d, bool first) {
@@ -851,7 +876,7 @@ int fast_prepare(Model* m) {
 
 #define CONV_SHAPES(X) X(1, 1, 3) X(3, 1, 3) X(3, 2, 3) X(3, 1, 6) X(6, 1, 6) X(6, 2, 6) X(6, 1, 12) X(12, 1, 12) X(12, 2, 12)
 
-bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
+bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool) {
     if (!conv_supported(m, o)) return false;
     PgPlan& pl = g_plans[m];
     auto it = pl.slot.find({&o, 0});
@@ -861,6 +886,7 @@ bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
     a.bmat = pl.bmat + it->second;
     a.bias = m->p + o.b_off;
     a.dst = o.out.d.p;
+    a.pool_dst = pool ? pool->out.d.p : nullptr;     // the caller checked fast_pool_fusable(o, *pool)
     a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
     a.alpha = o.alpha;
     const int C = o.inA.d.C, NS = o.inB.d.C ? 2 : 1, CO = o.out.d.C;

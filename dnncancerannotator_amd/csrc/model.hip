@@ -371,13 +371,20 @@ int Model::forward(const float* x_dev, int B, bool training) {
     DN_TRY(fast_prepare(this));
     DN_TRY(ig_prepare(this));
 
-    for (Op& o : ops) {
+    const Op* pool_done = nullptr;      // a max-pool that rode in the preceding conv's epilogue
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+        Op& o = ops[oi];
         switch (o.type) {
             case OP_CONV: {
                 int Cin = o.inA.d.C + o.inB.d.C;
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d) + nelem(B, o.out.d));
                 double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
-                if (!generic && (fast_conv_fwd(this, B, o, bytes, flops) || ig_conv_fwd(this, B, o, bytes, flops))) break;
+                Op* pool = (!generic && oi + 1 < ops.size() && fast_pool_fusable(this, o, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
+                if (!generic && fast_conv_fwd(this, B, o, bytes + (pool ? 4.0 * nelem(B, pool->out.d) : 0.0), flops, pool)) {
+                    pool_done = pool;
+                    break;
+                }
+                if (!generic && ig_conv_fwd(this, B, o, bytes, flops)) break;
                 LAUNCH(this, "g_conv_fwd", bytes, flops,
                        g_conv_fwd(stream, B, o.inA.d, o.inB.d, p + o.w_off, p + o.b_off, o.out.d, o.k, o.alpha));
                 break;
@@ -399,6 +406,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 break;
             }
             case OP_POOL: {
+                if (pool_done == &o) break;          // computed by the conv that produced its input
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
                 if (!generic && fast_pool_fwd(this, B, o, bytes)) break;
                 LAUNCH(this, "g_pool_fwd", bytes, 0, g_pool_fwd(stream, B, o.inA.d, o.out.d, o.k));
