@@ -548,7 +548,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
 
 int Model::optimizer_step(float lr) {
     float gscale = 1.0f;
-    if (world > 1 && !dry) {
+    if (comm && !dry) {
         // one all-reduce over [gradients ..., loss]: MirroredStrategy's cross-replica sum (engine.py:262) [TF-2.6]
         ncclResult_t r = ncclAllReduce(g, g, (size_t)nT + 1, ncclFloat, ncclSum, comm, stream);
         if (r != ncclSuccess) { set_error("ncclAllReduce: %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
@@ -815,7 +815,8 @@ int dnnca_comm_init(void* model, int rank, int world, const void* unique_id, siz
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world %d/%d", rank, world); return DNNCA_EINVAL; }
     M->rank = rank;
     M->world = world;
-    if (world == 1) return DNNCA_OK;
+    // DNNCA_FORCE_RCCL: build a one-rank communicator too, so every collective of the DP path can be exercised on one GPU
+    if (world == 1 && !(getenv("DNNCA_FORCE_RCCL") && unique_id)) return DNNCA_OK;
     if (!unique_id || id_len < sizeof(ncclUniqueId)) { set_error("unique id too short"); return DNNCA_EINVAL; }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
@@ -833,7 +834,7 @@ int dnnca_comm_world(void* model, int* rank, int* world) {
 
 int dnnca_comm_broadcast_weights(void* model, int root) {
     MODEL(model);
-    if (M->world == 1) return DNNCA_OK;
+    if (!M->comm) return DNNCA_OK;
     struct { float* p; int64_t n; } bufs[4] = {{M->p, M->nT}, {M->state, M->nS}, {M->m, M->nT}, {M->v, M->nT}};
     for (auto& b : bufs) {
         if (b.n == 0) continue;
@@ -846,7 +847,7 @@ int dnnca_comm_broadcast_weights(void* model, int root) {
 
 int dnnca_comm_average_state(void* model) {
     MODEL(model);
-    if (M->world == 1 || M->nS == 0) return DNNCA_OK;
+    if (!M->comm || M->nS == 0) return DNNCA_OK;
     ncclResult_t r = ncclAllReduce(M->state, M->state, (size_t)M->nS, ncclFloat, ncclSum, M->comm, M->stream);
     if (r != ncclSuccess) { set_error("ncclAllReduce(state): %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
     g_scale(M->stream, (size_t)M->nS, M->state, 1.0f / (float)M->world);
@@ -857,7 +858,7 @@ int dnnca_comm_average_state(void* model) {
 int dnnca_comm_allreduce_host(void* model, float* values, int n, int op) {
     MODEL(model);
     if (n < 1 || n > 256 || !values) return DNNCA_EINVAL;
-    if (M->world == 1) return DNNCA_OK;
+    if (!M->comm) return DNNCA_OK;
     float* tmp = reinterpret_cast<float*>(M->conf_dev);
     HIP_TRY(hipMemcpyAsync(tmp, values, (size_t)n * 4, hipMemcpyHostToDevice, M->stream));
     ncclResult_t r = ncclAllReduce(tmp, tmp, (size_t)n, ncclFloat, op == 1 ? ncclMax : ncclSum, M->comm, M->stream);

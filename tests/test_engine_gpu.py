@@ -305,3 +305,19 @@ def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
     plan = set(r[0] for r in m.plan())
     assert any(k.startswith('pgbwd_') or k.startswith('ig_') for k in plan)              # the tuned kernels are the ones planned
     m.close()
+
+
+def test_rccl_one_rank_rehearsal(gpu):
+    """The RCCL calls of the DP path (unique id, communicator, gradient all-reduce on the step's stream, broadcast,
+    state average, host all-reduce) on a one-rank communicator: a sum over one rank is the identity, so weights, BN
+    state, gradients and losses equal the run without a communicator (up to the float-atomic run-to-run noise)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_one_rank.py')], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert max(out['diff'].values()) <= max(1e-5, 4 * max(out['noise'].values())), out
+    np.testing.assert_allclose(out['losses_plain'], out['losses_rccl'], rtol=1e-6)
+    assert out['red'] == [1.5, -2.0]

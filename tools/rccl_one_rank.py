@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""One-GPU rehearsal of the data-parallel path: with DNNCA_FORCE_RCCL=1 a one-rank RCCL communicator is created and
+the gradient all-reduce, weight broadcast, state average and host all-reduce all go through RCCL.  A sum over one rank is
+the identity, so every result must equal the run without a communicator up to the run-to-run noise of the float
+atomics in the weight-gradient reduction.  Prints JSON."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dnncancerannotator_amd import device as dev                      # noqa: E402
+from dnncancerannotator_amd.synthetic import synthetic_batch         # noqa: E402
+
+
+def run(force):
+    if force:
+        os.environ['DNNCA_FORCE_RCCL'] = '1'
+    else:
+        os.environ.pop('DNNCA_FORCE_RCCL', None)
+    m = dev.DeviceModel('unet', 1, 64, 64, 4, n_filters_first=4, n_downsample=2, rate=2, kernel_size=3, conv_stride=1,
+                        bn=True, padding='same')
+    m.init_glorot(seed=2)
+    m.comm_init(0, 1, dev.DeviceModel.comm_unique_id() if force else None)
+    m.comm_broadcast_weights(0)
+    x, y = synthetic_batch(4, 64, 64, 1)
+    losses = [float(m.train_step(x, y, 1e-3, m.loss_cfg(weight_mul=3.0)).loss) for _ in range(3)]
+    m.comm_average_state()
+    red = m.comm_allreduce([1.5, -2.0], op='max').tolist()
+    out = dict(losses=losses, params=m.get_params(), state=m.get_state(), grads=m.get_grads(), red=red)
+    m.close()
+    return out
+
+
+def main():
+    dev.init_device(0)
+    a, b = run(False), run(True)
+    c = run(False)       # run-to-run noise floor (weight gradients are accumulated with float atomics)
+    diff = {k: float(np.abs(a[k] - b[k]).max() / (np.abs(a[k]).max() + 1e-30)) for k in ('params', 'state', 'grads')}
+    noise = {k: float(np.abs(a[k] - c[k]).max() / (np.abs(a[k]).max() + 1e-30)) for k in ('params', 'state', 'grads')}
+    print(json.dumps(dict(diff=diff, noise=noise, losses_plain=a['losses'], losses_rccl=b['losses'], red=b['red'])))
+
+
+if __name__ == '__main__':
+    main()
