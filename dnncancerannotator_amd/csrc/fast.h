@@ -13,6 +13,9 @@ unsigned long long* fast_debug_stamps(Model* m);   // tuning aid: in-kernel s_me
 bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool);
 bool fast_pool_fusable(const Model* m, const Op& conv, const Op& pool);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
+// kernels_first.hip: the one-channel-input 3x3 convs (first layer of every encoder)
+bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops);
+bool fast_first_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 bool fast_pool_fwd(Model* m, int B, Op& o, double bytes);
 bool fast_pool_bwd(Model* m, int B, Op& o, double bytes);
 bool fast_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops);

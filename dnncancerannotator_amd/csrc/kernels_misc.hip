@@ -505,52 +505,87 @@ bool fast_label_stats(Model* m, size_t n, const float* y) {
 
 // ================================================================================================ batch normalisation
 // Tuned BatchNormalization for C % 4 == 0 with (C/4) | 256 (16..1024 channels): one thread owns a 4-channel group of a
-// pixel (16-byte loads), the 256/(C/4) pixel lanes of a block stride over its pixel range, partial sums meet in LDS and
-// leave the block as ONE atomic per channel.  Statistics are raw moments (sum, sum of squares) accumulated in double at
-// block level; g_bn_finalize turns them into mean / biased variance.
+// pixel (16-byte loads, several in flight), the 256/(C/4) pixel lanes of a block walk chunks of pixels dealt round-robin,
+// partial sums meet in LDS and leave the block as one row of a [blocks][2C] partials table (same-address atomics from
+// hundreds of blocks cost more than the whole read pass: tools/micro/bn_reduce.hip).  A second small kernel folds the
+// table: forward -> mean / biased variance / moving statistics / coefficients (raw moments, accumulated in double),
+// backward -> dgamma / dbeta.
 namespace dnnca {
 
 static inline bool bn_fast_ok(const View& x) { return x.ps == x.C && x.C % 4 == 0 && 256 % (x.C / 4) == 0 && x.C >= 16; }
 
-__global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float* __restrict__ x, int C, double* __restrict__ ws) {
+__global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float* __restrict__ x, int C, double* __restrict__ part) {
     __shared__ double red[256][8];
     const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
-    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
-    const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
     double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
     float s[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
     int cnt = 0;
-    for (size_t p = p0 + pl; p < p1; p += PL) {
-        const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * cq);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        sq[0] = fmaf(v.x, v.x, sq[0]); sq[1] = fmaf(v.y, v.y, sq[1]); sq[2] = fmaf(v.z, v.z, sq[2]); sq[3] = fmaf(v.w, v.w, sq[3]);
-        if (++cnt == 64) {          // bound the float partials' rounding error
+    constexpr int U = 8;            // loads in flight per thread
+    const size_t chunk = (size_t)U * PL, nfull = npix / chunk;
+    for (size_t k = blockIdx.x; k < nfull; k += gridDim.x) {
+        const size_t p = k * chunk + pl;
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(x + (p + (size_t)u * PL) * C + 4 * cq);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
+            sq[0] = fmaf(v[u].x, v[u].x, sq[0]); sq[1] = fmaf(v[u].y, v[u].y, sq[1]);
+            sq[2] = fmaf(v[u].z, v[u].z, sq[2]); sq[3] = fmaf(v[u].w, v[u].w, sq[3]);
+        }
+        if (++cnt == 8) {           // bound the float partials' rounding error: 64 terms per flush
             for (int i = 0; i < 4; ++i) { ds[i] += s[i]; dq[i] += sq[i]; s[i] = 0.f; sq[i] = 0.f; }
             cnt = 0;
         }
     }
+    if (blockIdx.x == gridDim.x - 1)
+        for (size_t p = nfull * chunk + pl; p < npix; p += PL) {
+            const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * cq);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            sq[0] = fmaf(v.x, v.x, sq[0]); sq[1] = fmaf(v.y, v.y, sq[1]); sq[2] = fmaf(v.z, v.z, sq[2]); sq[3] = fmaf(v.w, v.w, sq[3]);
+        }
     for (int i = 0; i < 4; ++i) { ds[i] += s[i]; dq[i] += sq[i]; }
     for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = ds[i]; red[threadIdx.x][4 + i] = dq[i]; }
     __syncthreads();
-    if (threadIdx.x < G) {
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int l = 0; l < PL; ++l)
-            for (int i = 0; i < 8; ++i) a[i] += red[l * G + threadIdx.x][i];
-        for (int i = 0; i < 4; ++i) {
-            atomicAdd(ws + 4 * threadIdx.x + i, a[i]);
-            atomicAdd(ws + C + 4 * threadIdx.x + i, a[4 + i]);
-        }
+    // 2C outputs (sum, sumsq per channel), PL terms each
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        const int c = o % C, which = o / C;
+        double a = 0.0;
+        for (int l = 0; l < PL; ++l) a += red[l * G + (c >> 2)][4 * which + (c & 3)];
+        part[(size_t)blockIdx.x * 2 * C + o] = a;
     }
 }
 
+// fold of a [nb][2C] partials table: block = 32 channels x 32 row lanes (1024 threads), grid = ceil(C / 32)
+template <typename TP>
+__device__ __forceinline__ void bn_fold(const TP* __restrict__ part, int nb, int C, double& a0, double& a1, double (*red)[32][2]) {
+    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C)
+        for (int b = r; b < nb; b += 32) {
+            s0 += (double)part[(size_t)b * 2 * C + c];
+            s1 += (double)part[(size_t)b * 2 * C + C + c];
+        }
+    red[r][cl][0] = s0;
+    red[r][cl][1] = s1;
+    __syncthreads();
+    a0 = 0.0; a1 = 0.0;
+    if (r == 0)
+        for (int l = 0; l < 32; ++l) { a0 += red[l][cl][0]; a1 += red[l][cl][1]; }
+}
+
 // raw moments -> coefficients (and the moving statistics in training): same contract as g_bn_finalize
-__global__ void k_bn_finalize_raw(int C, double n, const double* __restrict__ ws, const float* __restrict__ gamma,
-                                  const float* __restrict__ beta, float* __restrict__ mmean, float* __restrict__ mvar,
-                                  float* __restrict__ coef, float momentum, float eps) {
-    int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const double mean_d = ws[c] / n;
-    double var_d = ws[C + c] / n - mean_d * mean_d;
+__global__ __launch_bounds__(1024) void k_bn_fold_stats(int C, int nb, double n, const double* __restrict__ part,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ mmean, float* __restrict__ mvar,
+                                                        float* __restrict__ coef, float momentum, float eps) {
+    __shared__ double red[32][32][2];
+    double sum, sumsq;
+    bn_fold(part, nb, C, sum, sumsq, red);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    const double mean_d = sum / n;
+    double var_d = sumsq / n - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d, var = (float)var_d;
     const float unbiased = (float)(var_d * (n > 1.0 ? n / (n - 1.0) : 1.0));
@@ -562,6 +597,17 @@ __global__ void k_bn_finalize_raw(int C, double n, const double* __restrict__ ws
     coef[C + c] = beta[c] - mean * sc;
     coef[2 * C + c] = mean;
     coef[3 * C + c] = inv;
+}
+
+__global__ __launch_bounds__(1024) void k_bn_fold_bwd(int C, int nb, const float* __restrict__ part, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta) {
+    __shared__ double red[32][32][2];
+    double g, b;
+    bn_fold(part, nb, C, g, b, red);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    dgamma[c] += (float)g;
+    dbeta[c] += (float)b;
 }
 
 __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* __restrict__ x, float* __restrict__ y, int C,
@@ -579,30 +625,43 @@ __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* _
 
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const float* __restrict__ x, const float* __restrict__ dy,
                                                             int C, int dps, const float* __restrict__ coef,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            float* __restrict__ part) {
     __shared__ float red[256][8];
     const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
-    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
-    const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
     const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
     float sg[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
-    for (size_t p = p0 + pl; p < p1; p += PL) {
-        const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * cq);
-        const float4 d = *reinterpret_cast<const float4*>(dy + p * dps + 4 * cq);
-        sg[0] = fmaf(d.x, (v.x - mean.x) * inv.x, sg[0]); sg[1] = fmaf(d.y, (v.y - mean.y) * inv.y, sg[1]);
-        sg[2] = fmaf(d.z, (v.z - mean.z) * inv.z, sg[2]); sg[3] = fmaf(d.w, (v.w - mean.w) * inv.w, sg[3]);
-        sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
+    constexpr int U = 4;            // 8 loads in flight per thread
+    const size_t chunk = (size_t)U * PL, nfull = npix / chunk;
+    for (size_t k = blockIdx.x; k < nfull; k += gridDim.x) {
+        const size_t p = k * chunk + pl;
+        float4 v[U], d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = *reinterpret_cast<const float4*>(x + (p + (size_t)u * PL) * C + 4 * cq);
+            d[u] = *reinterpret_cast<const float4*>(dy + (p + (size_t)u * PL) * dps + 4 * cq);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sg[0] = fmaf(d[u].x, (v[u].x - mean.x) * inv.x, sg[0]); sg[1] = fmaf(d[u].y, (v[u].y - mean.y) * inv.y, sg[1]);
+            sg[2] = fmaf(d[u].z, (v[u].z - mean.z) * inv.z, sg[2]); sg[3] = fmaf(d[u].w, (v[u].w - mean.w) * inv.w, sg[3]);
+            sb[0] += d[u].x; sb[1] += d[u].y; sb[2] += d[u].z; sb[3] += d[u].w;
+        }
     }
+    if (blockIdx.x == gridDim.x - 1)
+        for (size_t p = nfull * chunk + pl; p < npix; p += PL) {
+            const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * cq);
+            const float4 d = *reinterpret_cast<const float4*>(dy + p * dps + 4 * cq);
+            sg[0] = fmaf(d.x, (v.x - mean.x) * inv.x, sg[0]); sg[1] = fmaf(d.y, (v.y - mean.y) * inv.y, sg[1]);
+            sg[2] = fmaf(d.z, (v.z - mean.z) * inv.z, sg[2]); sg[3] = fmaf(d.w, (v.w - mean.w) * inv.w, sg[3]);
+            sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
+        }
     for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = sg[i]; red[threadIdx.x][4 + i] = sb[i]; }
     __syncthreads();
-    if (threadIdx.x < G) {
-        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int l = 0; l < PL; ++l)
-            for (int i = 0; i < 8; ++i) a[i] += red[l * G + threadIdx.x][i];
-        for (int i = 0; i < 4; ++i) {
-            atomicAdd(dgamma + 4 * threadIdx.x + i, a[i]);
-            atomicAdd(dbeta + 4 * threadIdx.x + i, a[4 + i]);
-        }
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        const int c = o % C, which = o / C;
+        float a = 0.f;
+        for (int l = 0; l < PL; ++l) a += red[l * G + (c >> 2)][4 * which + (c & 3)];
+        part[(size_t)blockIdx.x * 2 * C + o] = a;
     }
 }
 
@@ -637,10 +696,23 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
     *o = r;
 }
 
+// partials table shared by all BN ops of a model (stream-ordered use); grown on demand
+static bool bn_scratch(Model* m, size_t bytes, void** out) {
+    if (bytes > m->bn_part_bytes) {
+        void* p = nullptr;
+        if (m->alloc(&p, bytes) != DNNCA_OK) return false;
+        m->bn_part = p;
+        m->bn_part_bytes = bytes;
+    }
+    *out = m->bn_part;
+    return true;
+}
+#define DN_TRYB(x) do { if (!(x)) return false; } while (0)
+
 static unsigned bn_blocks(size_t npix, int C) {
     const size_t PL = 256 / (C / 4);
-    size_t b = (npix + PL * 16 - 1) / (PL * 16);
-    if (b > 1024) b = 1024;
+    size_t b = (npix + PL * 32 - 1) / (PL * 32);
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     return (unsigned)b;
 }
@@ -652,11 +724,13 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
     const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
     const double tb = 4.0 * npix * C;
     if (training) {
-        if (!m->dry) (void)hipMemsetAsync(o.ws, 0, (size_t)2 * C * 8, m->stream);
+        const unsigned nb = bn_blocks(npix, C);
+        double* part = nullptr;
+        DN_TRYB(bn_scratch(m, (size_t)nb * 2 * C * 8, (void**)&part));
         LAUNCH(m, "bn_stats", tb, 3 * tb / 4,
-               hipLaunchKernelGGL(k_bn_stats_fast, dim3(bn_blocks(npix, C)), dim3(256), 0, m->stream, npix, o.inA.d.p, C, o.ws));
-        LAUNCH(m, "bn_finalize", 0, 0,
-               hipLaunchKernelGGL(k_bn_finalize_raw, dim3((C + 255) / 256), dim3(256), 0, m->stream, C, (double)npix, o.ws,
+               hipLaunchKernelGGL(k_bn_stats_fast, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, part));
+        LAUNCH(m, "bn_fold_stats", 16.0 * nb * C, 0,
+               hipLaunchKernelGGL(k_bn_fold_stats, dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, (double)npix, part,
                                   m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off, m->state + o.mv_off, o.coef, momentum, eps));
     } else {
         LAUNCH(m, "g_bn_finalize", 0, 0,
@@ -679,9 +753,15 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
     const int C = o.inA.d.C;
     const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
     const double tb = 4.0 * npix * C;
+    const unsigned nb = bn_blocks(npix, C);
+    float* part = nullptr;
+    DN_TRYB(bn_scratch(m, (size_t)nb * 2 * C * 8, (void**)&part));
     LAUNCH(m, "bn_bwd_reduce", 2 * tb, tb,
-           hipLaunchKernelGGL(k_bn_bwd_reduce_fast, dim3(bn_blocks(npix, C)), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C,
-                              o.out.g.ps, o.coef, m->g + o.w_off, m->g + o.b_off));
+           hipLaunchKernelGGL(k_bn_bwd_reduce_fast, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C,
+                              o.out.g.ps, o.coef, part));
+    LAUNCH(m, "bn_fold_bwd", 8.0 * nb * C, 0,
+           hipLaunchKernelGGL(k_bn_fold_bwd, dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, part, m->g + o.w_off,
+                              m->g + o.b_off));
     const size_t n4 = npix * (C / 4);
     LAUNCH(m, "bn_bwd_apply", 3 * tb, 2 * tb,
            hipLaunchKernelGGL(k_bn_bwd_apply_fast, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, m->stream, n4, o.inA.d.p,

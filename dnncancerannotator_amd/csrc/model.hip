@@ -384,7 +384,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                     pool_done = pool;
                     break;
                 }
-                if (!generic && ig_conv_fwd(this, B, o, bytes, flops)) break;
+                if (!generic && (fast_first_conv_fwd(this, B, o, bytes, flops) || ig_conv_fwd(this, B, o, bytes, flops))) break;
                 LAUNCH(this, "g_conv_fwd", bytes, flops,
                        g_conv_fwd(stream, B, o.inA.d, o.inB.d, p + o.w_off, p + o.b_off, o.out.d, o.k, o.alpha));
                 break;
@@ -479,7 +479,8 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     int Cin = o.inA.d.C + o.inB.d.C;
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d));
                     double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
-                    if (!generic && (fast_conv_bwd(this, B, o, ob, ib, flops) || ig_conv_bwd(this, B, o, ob, ib, flops))) break;
+                    if (!generic && (fast_conv_bwd(this, B, o, ob, ib, flops) || fast_first_conv_bwd(this, B, o, ob, ib, flops) ||
+                                     ig_conv_bwd(this, B, o, ob, ib, flops))) break;
                     if (o.maskA || o.maskB) { set_error("internal: masked conv gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     if (o.alpha >= 0.f && !o.premasked)
                         LAUNCH(this, "g_act_bwd", 3 * ob, ob / 4,
