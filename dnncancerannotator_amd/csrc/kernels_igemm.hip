@@ -637,6 +637,132 @@ __global__ __launch_bounds__(256) void k_igb_wgrad(ig::WgArgs p) {
     }
 }
 
+// weight gradient, bf16, 64 x 64 channel blocks (all unet_big layers): M = 64 input channels (16 per wave), N = 64
+// output channels, 9 taps, K = pixels.  One persistent block per CU (one wave per SIMD, the whole register file):
+//   * the NHWC tiles are staged as they are -- [pixel][64 ch] bf16 rows of 160 B -- with 8-byte stores, and the
+//     K-contiguous (pixel-major) MFMA fragments come out of ds_read_b64_tr_b16, the hardware transposing read: group kg of a
+//     wave reads pixels 4kg..4kg+3 of tile row 2s (first read) and of row 2s+1 (second read); the contraction index may be
+//     permuted freely as long as both operands agree, and this order makes every read bank-conflict free (160-B rows);
+//   * the next tile's global loads are issued into registers before the current tile's 144 MFMAs per wave and written to
+//     LDS after them;
+//   * X and dY are read once per (ci block, co block) pair instead of once per 16 input channels.
+constexpr int WRS = 80;                 // bf16 per staged pixel row: 64 channels + 16 pad
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row0, const bf16_t* row1) {
+    typedef bf16x4 __attribute__((address_space(3))) * lds4;
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)row0);
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)row1);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t ximg[PATCH * WRS];
+    __shared__ __attribute__((aligned(16))) bf16_t gimg[TY * TX * WRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int gq = (lane >> 2) & 3, gp = lane & 3;       // transposing read: lane 4*gq + gp of a group addresses row gq, columns 4gp..
+    const int c0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    const bool do_bias = p.dbias && blockIdx.y == 0 && wave == 0;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+
+    f32x4 acc[9][4], accb[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int XU = (PATCH * 16 + 255) / 256, GU = TY * TX * 16 / 256;      // 12 and 8 float4 per thread
+    float4 xr[XU], gr[GU];
+    auto issue = [&](int tile) {
+        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+        const int x0 = bx * TX, y0 = by * TY;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 256 * u, px = i >> 4, c4 = i & 15;
+            const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (px < PATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                xr[u] = *reinterpret_cast<const float4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.cs + c0 + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 256 * u, px = i >> 4, n4 = i & 15;
+            const int ly = px / TX, lx = px - ly * TX;
+            const int iy = y0 + ly, ix = x0 + lx;
+            gr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy < p.H && ix < p.W)
+                gr[u] = *reinterpret_cast<const float4*>(p.dz + (((size_t)b * p.H + iy) * p.W + ix) * p.cout + co0 + 4 * n4);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 256 * u, px = i >> 4, c4 = i & 15;
+            if (px >= PATCH) continue;
+            bf16x4 h;
+            h[0] = (bf16_t)xr[u].x; h[1] = (bf16_t)xr[u].y; h[2] = (bf16_t)xr[u].z; h[3] = (bf16_t)xr[u].w;
+            *reinterpret_cast<bf16x4*>(ximg + px * WRS + 4 * c4) = h;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 256 * u, px = i >> 4, n4 = i & 15;
+            bf16x4 h;
+            h[0] = (bf16_t)gr[u].x; h[1] = (bf16_t)gr[u].y; h[2] = (bf16_t)gr[u].z; h[3] = (bf16_t)gr[u].w;
+            *reinterpret_cast<bf16x4*>(gimg + px * WRS + 4 * n4) = h;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    // per-lane bases of the transposing reads (bf16 elements)
+    const int xbase = (4 * q + gq) * WRS + 16 * wave + 4 * gp;
+    const int gbase = (4 * q + gq) * WRS + 4 * gp;
+#pragma unroll 1
+    for (; tile < ntiles; tile += p.psplit) {
+        lds_barrier();              // the previous tile's fragment reads are complete
+        commit();
+        if (tile + p.psplit < ntiles) issue(tile + p.psplit);
+        lds_barrier();
+#pragma unroll 1
+        for (int s = 0; s < TY / 2; ++s) {
+            bf16x8 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bv[j] = tr_frag(gimg + gbase + (2 * s * TX) * WRS + 16 * j, gimg + gbase + ((2 * s + 1) * TX) * WRS + 16 * j);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t % 3;
+                const bf16x8 av = tr_frag(ximg + xbase + ((2 * s + dy) * (TX + 2) + dx) * WRS,
+                                          ximg + xbase + ((2 * s + 1 + dy) * (TX + 2) + dx) * WRS);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[t][j], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bv[j], accb[j], 0, 0, 0);
+            }
+        }
+    }
+    // D[ci = 16 wave + 4q + i][co = 16j + m16]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(p.dw + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wave + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
+    if (do_bias && q == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(p.dbias + co0 + 16 * j + m16, accb[j][0]);
+    }
+}
+
 }  // namespace igb
 
 // ================================================================================================ host side
@@ -796,7 +922,14 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         w.psplit = psplit;
         dim3 grid(psplit, w.cs / ig::CK, CO / (16 * nn));
         const double bb = (out_bytes + in_bytes) / (CB ? 2 : 1), ff = flops / (CB ? 2 : 1);
-        if (use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
+        if (use_bf16(m, o) && CO % 64 == 0 && w.cs % 64 == 0) {
+            const int combos64 = (w.cs / 64) * (CO / 64);
+            int ps = (256 + combos64 - 1) / combos64;
+            if (ps > ntiles) ps = ntiles;
+            w.psplit = ps < 1 ? 1 : ps;
+            LAUNCH(m, "igb_wgrad64", bb, ff,
+                   hipLaunchKernelGGL(igb::k_igb_wgrad64, dim3(w.psplit, w.cs / 64, CO / 64), dim3(256), 0, m->stream, w));
+        } else if (use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
         else if (use_bf16(m, o) && nn == 2) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<2>), grid, dim3(256), 0, m->stream, w));
         else if (nn == 4) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<4>), grid, dim3(256), 0, m->stream, w));
         else if (nn == 2) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<2>), grid, dim3(256), 0, m->stream, w));
