@@ -448,10 +448,21 @@ using ig::ConvArgs;
 //                                            wd[t][ci][co] = w[8-t][ci][co] (data gradient: K = co contiguous)
 struct PrepDesc {
     int w_off, cin, cout;
+    int kind;                // 0: 3x3 conv kernel [9][ci][co]; 1: transposed-conv kernel [4][co][ci]
 };
 __global__ void k_igb_prep(const PrepDesc* __restrict__ descs, const float* __restrict__ params, bf16_t* __restrict__ wf,
                            bf16_t* __restrict__ wd) {
     const PrepDesc d = descs[blockIdx.y];
+    if (d.kind == 1) {          // Conv2DTranspose [ae][co][ci]: forward wants K = ci contiguous (as stored), dgrad K = co
+        const int n = 4 * d.cin * d.cout;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const int ci = i % d.cin, co = (i / d.cin) % d.cout, ae = i / (d.cin * d.cout);
+            const float v = params[d.w_off + i];
+            wf[d.w_off + i] = (bf16_t)v;
+            wd[d.w_off + ((size_t)ae * d.cin + ci) * d.cout + co] = (bf16_t)v;
+        }
+        return;
+    }
     const int n = 9 * d.cin * d.cout;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int co = i % d.cout, ci = (i / d.cout) % d.cin, t = i / (d.cin * d.cout);
@@ -891,6 +902,231 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 transposed conv
+// Conv2DTranspose(k = s = 2) under dtype bf16: four 1x1 GEMMs (one per output parity) that share their input tile.  All
+// three passes are HBM passes over the 4x larger output tensor; the point of these kernels is to read / write every
+// tensor once (the f32 kernels re-read the input per parity and per 16-channel chunk).
+using ig::TcArgs;
+using ig::tc_outpix;
+
+// forward: block = 128 input pixels x 64 output channels x 4 parities; K = Cin in chunks of 32
+__global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t* __restrict__ w16) {
+    __shared__ __attribute__((aligned(16))) bf16_t a_lds[128 * RS];
+    __shared__ __attribute__((aligned(16))) bf16_t b_lds[4 * 64 * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int p0 = blockIdx.x * 128, co0 = blockIdx.y * 64;
+    f32x4 acc[4][2][4];
+#pragma unroll
+    for (int ae = 0; ae < 4; ++ae)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ae][r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cc = 0; cc < p.cin; cc += CK) {
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + px < p.npix) v = *reinterpret_cast<const float4*>(p.in + (size_t)(p0 + px) * p.cin + cc + 4 * c4);
+            bf16x4 h;
+            h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+            *reinterpret_cast<bf16x4*>(a_lds + px * RS + 4 * c4) = h;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, part = i & 3, r = i >> 2;         // r = ae * 64 + n
+            const int ae = r >> 6, n = r & 63;
+            *reinterpret_cast<uint4*>(b_lds + r * RS + 8 * part) =
+                *reinterpret_cast<const uint4*>(w16 + ((size_t)ae * p.cout + co0 + n) * p.cin + cc + 8 * part);
+        }
+        lds_barrier();
+        bf16x8 av[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) av[r] = *reinterpret_cast<const bf16x8*>(a_lds + (32 * wave + 16 * r + m16) * RS + 8 * q);
+#pragma unroll
+        for (int ae = 0; ae < 4; ++ae)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(b_lds + (ae * 64 + 16 * j + m16) * RS + 8 * q);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[ae][r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[r], bv, acc[ae][r][j], 0, 0, 0);
+            }
+    }
+    float bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias[j] = p.bias[co0 + 16 * j + m16];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = p0 + 32 * wave + 16 * r + 4 * q + i;
+            if (px >= p.npix) continue;
+#pragma unroll
+            for (int ae = 0; ae < 4; ++ae) {
+                float* op = p.out + tc_outpix(px, ae >> 1, ae & 1, p.H, p.W) * p.cout + co0 + m16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) op[16 * j] = acc[ae][r][j][i] + bias[j];
+            }
+        }
+}
+
+// data gradient: din[p][ci] = sum_{ae,co} dout[out(p,ae)][co] * W[ae][co][ci]; block = 128 pixels x 64 input channels,
+// K = 4 x Cout in chunks of 32; w16 = [ae][ci][co] (K = co contiguous)
+__global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16_t* __restrict__ w16) {
+    __shared__ __attribute__((aligned(16))) bf16_t a_lds[128 * RS];
+    __shared__ __attribute__((aligned(16))) bf16_t b_lds[64 * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int p0 = blockIdx.x * 128, n0 = blockIdx.y * 64;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ar[4];
+    uint4 br;
+    auto issue = [&](int kc) {
+        const int ae = kc / p.cout, cc = kc - ae * p.cout;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
+            ar[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + px < p.npix)
+                ar[u] = *reinterpret_cast<const float4*>(p.dout + tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + cc + 4 * c4);
+        }
+        br = *reinterpret_cast<const uint4*>(w16 + ((size_t)ae * p.cin + n0 + (tid >> 2)) * p.cout + cc + 8 * (tid & 3));
+    };
+    issue(0);
+#pragma unroll 1
+    for (int kc = 0; kc < 4 * p.cout; kc += CK) {
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
+            bf16x4 h;
+            h[0] = (bf16_t)ar[u].x; h[1] = (bf16_t)ar[u].y; h[2] = (bf16_t)ar[u].z; h[3] = (bf16_t)ar[u].w;
+            *reinterpret_cast<bf16x4*>(a_lds + px * RS + 4 * c4) = h;
+        }
+        *reinterpret_cast<uint4*>(b_lds + (tid >> 2) * RS + 8 * (tid & 3)) = br;
+        if (kc + CK < 4 * p.cout) issue(kc + CK);
+        lds_barrier();
+        bf16x8 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(b_lds + (16 * j + m16) * RS + 8 * q);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(a_lds + (32 * wave + 16 * r + m16) * RS + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[r][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = p0 + 32 * wave + 16 * r + 4 * q + i;
+            if (px >= p.npix) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = (size_t)px * p.cin + n0 + 16 * j + m16;
+                float v = acc[r][j][i];
+                if (p.acc) v += p.din[o];
+                if (p.mask) v *= p.mask[o] > 0.f ? 1.0f : p.alpha;
+                p.din[o] = v;
+            }
+        }
+}
+
+// weight gradient: dW[ae][co][ci] = sum_p dout[out(p,ae)][co] * in[p][ci]; block = 64 co x 64 ci x 4 parities, persistent
+// over tiles of 128 input pixels (K); same staging / transposing-read scheme as k_igb_wgrad64.
+__global__ __launch_bounds__(256, 1) void k_igb_tconv_wgrad64(TcArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t ximg[128 * WRS];
+    __shared__ __attribute__((aligned(16))) bf16_t gimg[4 * 128 * WRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
+    const int co0 = blockIdx.y * 64, n0 = blockIdx.z * 64;
+    const bool do_bias = p.dbias && blockIdx.z == 0;
+    const int ntiles = (p.npix + 127) / 128;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+    f32x4 acc[4][4], accb[4];
+#pragma unroll
+    for (int ae = 0; ae < 4; ++ae) {
+        accb[ae] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[ae][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float4 xr[8], gr[4][8];
+    auto issue = [&](int tile) {
+        const int p0 = tile * 128;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u, px = i >> 4, c4 = i & 15;
+            const bool ok = p0 + px < p.npix;
+            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) xr[u] = *reinterpret_cast<const float4*>(p.in + (size_t)(p0 + px) * p.cin + n0 + 4 * c4);
+#pragma unroll
+            for (int ae = 0; ae < 4; ++ae) {
+                gr[ae][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) gr[ae][u] = *reinterpret_cast<const float4*>(p.dout + tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + co0 + 4 * c4);
+            }
+        }
+    };
+    auto cvt = [](const float4& v) {
+        bf16x4 h;
+        h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+        return h;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u, px = i >> 4, c4 = i & 15;
+            *reinterpret_cast<bf16x4*>(ximg + px * WRS + 4 * c4) = cvt(xr[u]);
+#pragma unroll
+            for (int ae = 0; ae < 4; ++ae) *reinterpret_cast<bf16x4*>(gimg + (ae * 128 + px) * WRS + 4 * c4) = cvt(gr[ae][u]);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    const int xbase = (4 * q + gq) * WRS + 4 * gp;
+    const int gbase = (4 * q + gq) * WRS + 16 * wave + 4 * gp;
+#pragma unroll 1
+    for (; tile < ntiles; tile += p.psplit) {
+        lds_barrier();
+        commit();
+        if (tile + p.psplit < ntiles) issue(tile + p.psplit);
+        lds_barrier();
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = tr_frag(ximg + xbase + (32 * s) * WRS + 16 * j, ximg + xbase + (32 * s + 16) * WRS + 16 * j);
+#pragma unroll
+            for (int ae = 0; ae < 4; ++ae) {
+                const bf16x8 av = tr_frag(gimg + gbase + (ae * 128 + 32 * s) * WRS, gimg + gbase + (ae * 128 + 32 * s + 16) * WRS);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ae][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[ae][j], 0, 0, 0);
+                if (do_bias) accb[ae] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones, accb[ae], 0, 0, 0);
+            }
+        }
+    }
+    // D[co = 16 wave + 4q + i][ci = 16j + m16]
+#pragma unroll
+    for (int ae = 0; ae < 4; ++ae)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(p.dw + ((size_t)ae * p.cout + co0 + 16 * wave + 4 * q + i) * p.cin + n0 + 16 * j + m16, acc[ae][j][i]);
+    if (do_bias && m16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            atomicAdd(p.dbias + co0 + 16 * wave + 4 * q + i, (accb[0][i] + accb[1][i]) + (accb[2][i] + accb[3][i]));
+    }
+}
+
 }  // namespace igb
 
 // ================================================================================================ host side
@@ -927,6 +1163,11 @@ static bool use_bf16(const Model* m, const Op& o) {
     return m->desc.dtype == DNNCA_BF16 && o.inA.d.C % 32 == 0 && o.inB.d.C % 32 == 0 && o.out.d.C % 32 == 0;
 }
 
+bool ig_tconv_supported(const Model* m, const Op& o);
+static bool use_bf16_tc(const Model* m, const Op& o) {
+    return m->desc.dtype == DNNCA_BF16 && o.inA.d.C % 64 == 0 && o.out.d.C % 64 == 0;
+}
+
 int ig_prepare(Model* m) {
     if (m->desc.flags & 1) return DNNCA_OK;
     IgPlan& pl = g_ig[m];
@@ -941,9 +1182,16 @@ int ig_prepare(Model* m) {
         }
         for (const Op& o : m->ops) {
             if (!ig_conv_supported(m, o) || !use_bf16(m, o)) continue;
-            igb::PrepDesc d{(int)o.w_off, o.inA.d.C + o.inB.d.C, o.out.d.C};
+            igb::PrepDesc d{(int)o.w_off, o.inA.d.C + o.inB.d.C, o.out.d.C, 0};
             pl.preps.push_back(d);
             int n = 9 * d.cin * d.cout;
+            if (n > pl.max_wb) pl.max_wb = n;
+        }
+        for (const Op& o : m->ops) {
+            if (!ig_tconv_supported(m, o) || !use_bf16_tc(m, o)) continue;
+            igb::PrepDesc d{(int)o.w_off, o.inA.d.C, o.out.d.C, 1};
+            pl.preps.push_back(d);
+            int n = 4 * d.cin * d.cout;
             if (n > pl.max_wb) pl.max_wb = n;
         }
         if (!pl.preps.empty()) {
@@ -1119,6 +1367,12 @@ static ig::TcArgs tc_args(Model* m, int B, Op& o) {
 bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
     if (!ig_tconv_supported(m, o)) return false;
     ig::TcArgs a = tc_args(m, B, o);
+    if (use_bf16_tc(m, o)) {
+        IgPlan& pl = g_ig[m];
+        LAUNCH(m, "igb_tconv_fwd", bytes, flops,
+               hipLaunchKernelGGL(igb::k_igb_tconv_fwd, dim3((a.npix + 127) / 128, a.cout / 64), dim3(256), 0, m->stream, a, pl.wf + o.w_off));
+        return true;
+    }
     const int nn = pick_nn(a.cout);
     dim3 grid((a.npix + 127) / 128, a.cout / (16 * nn), 4);
     if (nn == 4) LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd<4>), grid, dim3(256), 0, m->stream, a));
@@ -1130,6 +1384,18 @@ bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
 bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops) {
     if (!ig_tconv_supported(m, o)) return false;
     ig::TcArgs a = tc_args(m, B, o);
+    if (use_bf16_tc(m, o)) {
+        IgPlan& pl = g_ig[m];
+        const int ntiles = (a.npix + 127) / 128, combos = (a.cout / 64) * (a.cin / 64);
+        int ps = (256 + combos - 1) / combos;
+        if (ps > ntiles) ps = ntiles;
+        a.psplit = ps < 1 ? 1 : ps;
+        LAUNCH(m, "igb_tconv_wgrad", out_bytes + in_bytes, flops,
+               hipLaunchKernelGGL(igb::k_igb_tconv_wgrad64, dim3(a.psplit, a.cout / 64, a.cin / 64), dim3(256), 0, m->stream, a));
+        LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops,
+               hipLaunchKernelGGL(igb::k_igb_tconv_dgrad, dim3((a.npix + 127) / 128, a.cin / 64), dim3(256), 0, m->stream, a, pl.wd + o.w_off));
+        return true;
+    }
     {
         const int nn = pick_nn(a.cin);
         const int ntiles = (a.npix + 127) / 128;

@@ -156,12 +156,28 @@ def _to_bf16(a):
     return u.astype(np.uint32).view(np.float32).astype(np.float64)
 
 
-def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch):
+@pytest.mark.parametrize('f0', [32, 64])
+def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch, f0):
     """dtype bf16: the implicit-GEMM kernels round their operands (activations, gradients, weights) to bf16 while staging
     and accumulate in fp32.  The oracle is made to do exactly that (operands of every 3x3 conv rounded to bf16, float64
     accumulation), so the comparison isolates the kernels' indexing from bf16 noise: what remains is fp32 accumulation
-    order (tolerances as in the fp32 parity tests).  Network: every 3x3 conv has 32..64 channels (all on the bf16 path)."""
+    order (tolerances as in the fp32 parity tests).  Network: every 3x3 conv has f0..2*f0 channels (all on the bf16 path:
+    f0 = 32 runs the 16/32-channel-tile kernels, f0 = 64 the 64-channel-tile ones); transposed convs whose channel counts
+    are multiples of 64 contract in bf16 as well."""
     fwd0, bwd0 = O.conv2d_fwd, O.conv2d_bwd
+    tfwd0, tbwd0 = O.tconv_fwd, O.tconv_bwd
+
+    def tc_bf16(w):
+        return w.shape[2] % 64 == 0 and w.shape[3] % 64 == 0
+
+    def tfwd(x, w, b):
+        return tfwd0(_to_bf16(x), _to_bf16(w), b) if tc_bf16(w) else tfwd0(x, w, b)
+
+    def tbwd(cache, dy):
+        return tbwd0(cache, _to_bf16(dy)) if tc_bf16(cache[1]) else tbwd0(cache, dy)
+
+    monkeypatch.setattr(O, 'tconv_fwd', tfwd)
+    monkeypatch.setattr(O, 'tconv_bwd', tbwd)
 
     def fwd(x, w, b, padding, alpha=None):
         if w.shape[0] == 1:
@@ -177,7 +193,7 @@ def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch):
 
     monkeypatch.setattr(O, 'conv2d_fwd', fwd)
     monkeypatch.setattr(O, 'conv2d_bwd', bwd)
-    opts = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', n_filters_first=32, n_downsample=2, bn=False)
+    opts = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', n_filters_first=f0, n_downsample=2, bn=False)
     spec = O.ModelSpec('unet', 32, **opts)
     params = Hp.perturbed_params(spec, np.float64)
     rng = np.random.default_rng(3)
@@ -200,7 +216,10 @@ def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch):
     # activations differ by a fraction of a bf16 ulp (see above), which flips some ReLU masks: a few 1e-2, not the O(1) of an indexing error
     assert err_l2 <= 4e-2 and Hp.rel_err(g, gref) <= 4e-2, (err_l2, Hp.rel_err(g, gref))
     prof = dict((r[0], r) for r in m.plan())
-    assert 'igb_conv_fwd' in prof and 'igb_wgrad' in prof and 'igb_conv_dgrad' in prof        # the bf16 kernels are the ones that ran
+    assert 'igb_conv_fwd' in prof and 'igb_conv_dgrad' in prof and 'igb_tconv_fwd' in prof    # the bf16 kernels are the ones that ran
+    assert 'igb_wgrad' in prof                      # 32-channel sources (the first conv's input has 32 channels)
+    assert ('ig_tconv_fwd' in prof) == (f0 == 32)   # f0 = 64: every transposed conv contracts in bf16
+    assert 'igb_wgrad64' in prof and 'igb_tconv_wgrad' in prof and 'igb_tconv_dgrad' in prof
     m.close()
 
 
