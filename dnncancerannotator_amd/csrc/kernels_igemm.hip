@@ -436,6 +436,7 @@ namespace igb {
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // register-resident 16-byte staging word (HIP's uint4 struct arrays end up in scratch)
 
 constexpr int TY = ig::TY, TX = ig::TX, PATCH = ig::PATCH;
 constexpr int CK = 32;                  // K elements per staged chunk = one 16x16x32 MFMA
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_conv2(ConvArgs p, const bf16_t* 
 
     constexpr int AU = (PATCH2 * 8 + 255) / 256, BU = 9 * 64 * 4 / 256;        // 11 float4 and 9 uint4 per thread
     float4 ar[AU];
-    uint4 br[BU];
+    u32x4 br[BU];
     auto issue = [&](int cc) {
         const bool second = cc >= p.c_src0;
         const float* src = second ? p.src[1] : p.src[0];
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_conv2(ConvArgs p, const bf16_t* 
         for (int u = 0; u < BU; ++u) {
             const int i = tid + 256 * u, part = i & 3, r = i >> 2;         // r = tap * 64 + n
             const int tap = r >> 6, n = r & 63;
-            br[u] = *reinterpret_cast<const uint4*>(w16 + ((size_t)tap * nout + co0 + n) * kin + cc + 8 * part);
+            br[u] = *reinterpret_cast<const u32x4*>(w16 + ((size_t)tap * nout + co0 + n) * kin + cc + 8 * part);
         }
     };
     auto commit = [&]() {
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_conv2(ConvArgs p, const bf16_t* 
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
             const int i = tid + 256 * u, part = i & 3, r = i >> 2;
-            *reinterpret_cast<uint4*>(b_lds + r * RS + 8 * part) = br[u];
+            *reinterpret_cast<u32x4*>(b_lds + r * RS + 8 * part) = br[u];
         }
     };
 
@@ -772,6 +773,230 @@ __global__ __launch_bounds__(256, 2) void k_igb_conv2(ConvArgs p, const bf16_t* 
                 }
                 p.dst[which][o] = v;
             }
+        }
+    }
+}
+
+// forward / data gradient, bf16, persistent and software-pipelined (one block per CU, the whole register file):
+//   work item = (pixel tile, channel tile, K chunk); a block walks its items in order, accumulators restart at chunk 0;
+//   two LDS buffers: while the MFMAs of item i read buffer i&1, the registers prefetched for item i+1 are converted and
+//   written into the other buffer and the global loads of item i+2 are issued, both in eight slices that sit between the
+//   nine tap steps -- one barrier per item, and the prefetch runs across tile boundaries, so the first chunk of the next
+//   tile is already in LDS when a tile's epilogue starts;
+//   fragments are double-buffered in registers: the LDS reads of tap step s+1 are issued before the 16 MFMAs of step s;
+//   taps are walked dx-major so that the six A rows of a dx serve its three dy taps (18 instead of 24 reads per 48 MFMAs);
+//   global loads are raw buffer loads: out-of-image patch pixels get an out-of-range offset and come back as zeros, no
+//   branches; epilogue through LDS (the buffer just read): every pixel's 64 output channels leave as one 256-byte row of
+//   float4 stores (bias + activation, or accumulate + act' mask for the data gradient, on float4s as well).
+constexpr int BUF3 = (PATCH2 + 9 * 64) * RS + 64;   // bf16 elements per LDS buffer: A patch + 9-tap weight slab (72,000 B) + a dump row for the idle lanes of the last A element
+constexpr int OSTR = 68;                            // floats per pixel row of the epilogue image
+constexpr unsigned BUF_FLAGS = 0x00020000u;         // raw buffer descriptor word 3 (gfx9 family)
+constexpr unsigned OOB = 0x80000000u;               // beyond every tensor here: the buffer load returns zeros
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* __restrict__ w16) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * BUF3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
+    const int nco = nout >> 6, ntiles = p.tiles_x * p.tiles_y * p.B, nunits = ntiles * nco;
+    const int nchunks = kin / CK;
+    const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+    const int my_units = (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nitems = my_units * nchunks;
+    if (nitems <= 0) return;
+
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * 4), nbytes1 = (unsigned)(npix * p.c_src1 * 4);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)w16, 0, (unsigned)((size_t)9 * nout * kin * 2), BUF_FLAGS);
+
+    struct Unit { int b, y0, x0, co0; };
+    auto unit_of = [&](int k) {
+        const int id = blockIdx.x + k * gridDim.x;
+        int tile, cot;
+        if (xcd_map) {              // ids congruent mod 8 share an XCD: keep a tile's channel blocks there
+            const int xcd = id & 7, j = id >> 3;
+            cot = j % nco;
+            tile = (j / nco) * 8 + xcd;
+        } else {
+            cot = id % nco;
+            tile = id / nco;
+        }
+        Unit u;
+        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y;
+        u.b = tile / (p.tiles_x * p.tiles_y);
+        u.x0 = bx * T2; u.y0 = by * T2; u.co0 = cot * 64;
+        return u;
+    };
+
+    // ---- staging geometry of this thread: A element v = patch pixel (tid >> 3) + 32 v, channels 4 (tid & 7)..;
+    //      B element v = tap v, output channel tid >> 2, K part tid & 3
+    constexpr int AU = (PATCH2 * 8 + 255) / 256, BU = 9;
+    const int c4 = tid & 7, bn = tid >> 2, bpart = tid & 3;
+    int a_ly[AU], a_lx[AU];
+#pragma unroll
+    for (int v = 0; v < AU; ++v) {
+        const int px = (tid >> 3) + 32 * v;
+        a_ly[v] = px / (T2 + 2);
+        a_lx[v] = px - a_ly[v] * (T2 + 2);
+        if (px >= PATCH2) a_ly[v] = -4096;          // never inside an image
+    }
+    f32x4 ar[AU];
+    u32x4 br[BU];
+    // item being staged (uniform per block)
+    struct Stage { int b, y0, x0, co0, cc, cs, c0; unsigned oob; __amdgpu_buffer_rsrc_t rs; };
+    auto stage_of = [&](int item) {            // items past the end stage nothing: every offset is out of range
+        const int valid = item < nitems;
+        item = valid ? item : 0;
+        const int k = item / nchunks;
+        const Unit u = unit_of(k);
+        Stage st;
+        st.b = u.b; st.y0 = u.y0; st.x0 = u.x0; st.co0 = u.co0;
+        st.cc = (item - k * nchunks) * CK;
+        const bool second = st.cc >= p.c_src0;
+        st.cs = second ? p.c_src1 : p.c_src0;
+        st.c0 = second ? st.cc - p.c_src0 : st.cc;
+        st.oob = valid ? 0u : OOB;          // OR-ed into every offset
+        // descriptor of this chunk's source built from scalar selects (no branch inside the MFMA stream)
+        st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.src[1] : p.src[0]), 0, second ? nbytes1 : nbytes0, BUF_FLAGS);
+        return st;
+    };
+    auto issue_a = [&](const Stage& st, int v) {
+        const int iy = st.y0 - 1 + a_ly[v], ix = st.x0 - 1 + a_lx[v];
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned off = (ok ? (unsigned)(((((st.b * p.H + iy) * p.W + ix) * st.cs) + st.c0 + 4 * c4) * 4) : OOB) | st.oob;
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
+        ar[v] = __builtin_bit_cast(f32x4, t);
+    };
+    auto issue_b = [&](const Stage& st, int v) {
+        const unsigned off = (unsigned)((((v * nout + st.co0 + bn) * kin) + st.cc + 8 * bpart) * 2) | st.oob;
+        br[v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0);
+    };
+    auto commit_a = [&](bf16_t* buf, int v) {
+        const int px = (tid >> 3) + 32 * v;
+        bf16x4 h;
+        h[0] = (bf16_t)ar[v][0]; h[1] = (bf16_t)ar[v][1]; h[2] = (bf16_t)ar[v][2]; h[3] = (bf16_t)ar[v][3];
+        // branch-free: lanes past the patch (last element only) write into the buffer's dump row
+        *reinterpret_cast<bf16x4*>(buf + (px < PATCH2 ? px * RS : (PATCH2 + 9 * 64) * RS) + 4 * c4) = h;
+    };
+    auto commit_b = [&](bf16_t* buf, int v) {
+        *reinterpret_cast<u32x4*>(buf + PATCH2 * RS + (64 * v + bn) * RS + 8 * bpart) = br[v];
+    };
+
+    f32x4 acc[4][4];
+    // ---- prologue: item 0 into buffer 0, item 1 into registers
+    {
+        const Stage s0 = stage_of(0);
+#pragma unroll
+        for (int v = 0; v < AU; ++v) issue_a(s0, v);
+#pragma unroll
+        for (int v = 0; v < BU; ++v) issue_b(s0, v);
+#pragma unroll
+        for (int v = 0; v < AU; ++v) commit_a(lds, v);
+#pragma unroll
+        for (int v = 0; v < BU; ++v) commit_b(lds, v);
+        if (nitems > 1) {
+            const Stage s1 = stage_of(1);
+#pragma unroll
+            for (int v = 0; v < AU; ++v) issue_a(s1, v);
+#pragma unroll
+            for (int v = 0; v < BU; ++v) issue_b(s1, v);
+        }
+    }
+    lds_barrier();
+#pragma unroll 1
+    for (int it = 0; it < nitems; ++it) {
+        bf16_t* buf = lds + (it & 1) * BUF3;
+        bf16_t* other = lds + ((it & 1) ^ 1) * BUF3;
+        const int k = it / nchunks, chunk = it - k * nchunks;
+        const Stage nx = stage_of(it + 2);
+        if (chunk == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const bf16_t* a_lds = buf + ((4 * wave) * (T2 + 2) + m16) * RS + 8 * q;
+        const bf16_t* b_lds = buf + PATCH2 * RS + m16 * RS + 8 * q;
+        bf16x8 fa[2][6], fb[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) fa[0][rr] = *reinterpret_cast<const bf16x8*>(a_lds + (rr * (T2 + 2)) * RS);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(b_lds + (16 * j) * RS);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int g = s / 3, dy = s % 3;            // tap (dy, dx = g): weight slab index dy * 3 + g
+            if (s + 1 < 9) {                            // fragments of the next step
+                const int g1 = (s + 1) / 3, dy1 = (s + 1) % 3;
+                if (dy1 == 0) {
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) fa[g1 & 1][rr] = *reinterpret_cast<const bf16x8*>(a_lds + (rr * (T2 + 2) + g1) * RS);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(b_lds + ((dy1 * 3 + g1) * 64 + 16 * j) * RS);
+            }
+            if (s >= 1) {                               // staging slice s-1: elements {s-1, s-1+8}
+                const int v0 = s - 1, v1 = s + 7;
+                // unconditional (straight-line code the scheduler can weave between the MFMAs): past the last item the
+                // commit writes stale registers into the buffer nobody reads again and the loads are out of range
+                commit_a(other, v0);
+                issue_a(nx, v0);
+                if (v1 < AU) { commit_a(other, v1); issue_a(nx, v1); }
+                commit_b(other, v0);
+                issue_b(nx, v0);
+                if (v1 < BU) { commit_b(other, v1); issue_b(nx, v1); }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][r + dy], fb[s & 1][j], acc[r][j], 0, 0, 0);
+        }
+        lds_barrier();
+        if (chunk == nchunks - 1) {
+            // ---- epilogue of unit k through the buffer that was just read
+            const Unit u = unit_of(k);
+            float* o_lds = reinterpret_cast<float*>(buf);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o_lds[((4 * wave + r) * T2 + 4 * q + i) * OSTR + 16 * j + m16] = acc[r][j][i];
+            lds_barrier();
+            const int which = u.co0 >= p.n_dst0;
+            const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? u.co0 - p.n_dst0 : u.co0;
+            float* dst = p.dst[which];
+            const int e4 = tid & 15;
+            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 0 && p.bias) bias = *reinterpret_cast<const float4*>(p.bias + u.co0 + 4 * e4);
+#pragma unroll 4
+            for (int v = 0; v < 16; ++v) {
+                const int px = (tid >> 4) + 16 * v, ly = px >> 4, lx = px & 15;
+                const int y = u.y0 + ly, x = u.x0 + lx;
+                if (y >= p.H || x >= p.W) continue;
+                float4 val = *reinterpret_cast<const float4*>(o_lds + px * OSTR + 4 * e4);
+                const size_t o = (((size_t)u.b * p.H + y) * p.W + x) * cw + cl + 4 * e4;
+                if (MODE == 0) {
+                    val.x += bias.x; val.y += bias.y; val.z += bias.z; val.w += bias.w;
+                    if (p.alpha >= 0.f) {
+                        val.x = val.x > 0.f ? val.x : p.alpha * val.x; val.y = val.y > 0.f ? val.y : p.alpha * val.y;
+                        val.z = val.z > 0.f ? val.z : p.alpha * val.z; val.w = val.w > 0.f ? val.w : p.alpha * val.w;
+                    }
+                } else {
+                    if (p.acc[which]) {
+                        const float4 t = *reinterpret_cast<const float4*>(dst + o);
+                        val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w;
+                    }
+                    if (p.mask[which]) {
+                        const float4 mk = *reinterpret_cast<const float4*>(p.mask[which] + o);
+                        val.x *= mk.x > 0.f ? 1.0f : p.alpha; val.y *= mk.y > 0.f ? 1.0f : p.alpha;
+                        val.z *= mk.z > 0.f ? 1.0f : p.alpha; val.w *= mk.w > 0.f ? 1.0f : p.alpha;
+                    }
+                }
+                *reinterpret_cast<float4*>(dst + o) = val;
+            }
+            lds_barrier();          // the next item's staging writes land in this buffer
         }
     }
 }
@@ -985,7 +1210,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 ar[4];
-    uint4 br;
+    u32x4 br;
     auto issue = [&](int kc) {
         const int ae = kc / p.cout, cc = kc - ae * p.cout;
 #pragma unroll
@@ -995,7 +1220,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16
             if (p0 + px < p.npix)
                 ar[u] = *reinterpret_cast<const float4*>(p.dout + tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + cc + 4 * c4);
         }
-        br = *reinterpret_cast<const uint4*>(w16 + ((size_t)ae * p.cin + n0 + (tid >> 2)) * p.cout + cc + 8 * (tid & 3));
+        br = *reinterpret_cast<const u32x4*>(w16 + ((size_t)ae * p.cin + n0 + (tid >> 2)) * p.cout + cc + 8 * (tid & 3));
     };
     issue(0);
 #pragma unroll 1
@@ -1008,7 +1233,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16
             h[0] = (bf16_t)ar[u].x; h[1] = (bf16_t)ar[u].y; h[2] = (bf16_t)ar[u].z; h[3] = (bf16_t)ar[u].w;
             *reinterpret_cast<bf16x4*>(a_lds + px * RS + 4 * c4) = h;
         }
-        *reinterpret_cast<uint4*>(b_lds + (tid >> 2) * RS + 8 * (tid & 3)) = br;
+        *reinterpret_cast<u32x4*>(b_lds + (tid >> 2) * RS + 8 * (tid & 3)) = br;
         if (kc + CK < 4 * p.cout) issue(kc + CK);
         lds_barrier();
         bf16x8 bv[4];
@@ -1247,6 +1472,12 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
         a2.tiles_x = (a.W + igb::T2 - 1) / igb::T2;
         a2.tiles_y = (a.H + igb::T2 - 1) / igb::T2;
         const unsigned nblocks = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / 64));
+        static const bool use_v2 = getenv("DNNCA_CONV2") != nullptr;          // tuning aid: the non-persistent variant
+        if (!use_v2 && a.n_dst0 % 64 == 0) {
+            const unsigned g = nblocks < 256u ? nblocks : 256u;
+            LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE>), dim3(g), dim3(256), 0, m->stream, a2, w16));
+            return;
+        }
         LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv2<MODE>), dim3(nblocks), dim3(256), 0, m->stream, a2, w16));
         return;
     }

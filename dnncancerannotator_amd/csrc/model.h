@@ -82,7 +82,8 @@ struct Model {
     int rank = 0, world = 1;
     // measurement
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int prof_mode = 0;
+    int prof_mode = 0;                   // 0 off, 1 every launch, 2 only `focus`, 3 every launch keyed by kernel@layer
+    const std::string* cur_op = nullptr;
     bool dry = false;
     std::string focus, plan_text;
     std::map<std::string, int> kid;

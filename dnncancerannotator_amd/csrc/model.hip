@@ -62,12 +62,14 @@ bool Model::begin(const char* name, double bytes, double flops) {
     if (prof_mode == 0) return true;
     if (prof_mode == 2 && focus != name) return true;
     int id;
-    auto it = kid.find(name);
+    std::string key = name;
+    if (prof_mode == 3 && cur_op) key += "@" + *cur_op;          // per-layer table
+    auto it = kid.find(key);
     if (it == kid.end()) {
         id = (int)kstats.size();
-        kid[name] = id;
+        kid[key] = id;
         KStat ks;
-        ks.name = name;
+        ks.name = key;
         kstats.push_back(ks);
     } else {
         id = it->second;
@@ -374,6 +376,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
     const Op* pool_done = nullptr;      // a max-pool that rode in the preceding conv's epilogue
     for (size_t oi = 0; oi < ops.size(); ++oi) {
         Op& o = ops[oi];
+        cur_op = &o.name;
         switch (o.type) {
             case OP_CONV: {
                 int Cin = o.inA.d.C + o.inB.d.C;
@@ -438,6 +441,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
 
 // ---------------------------------------------------------------------------------------------- loss + backward
 int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cfg, bool backward) {
+    cur_op = nullptr;
     const bool generic = desc.flags & 1;
     size_t npix = (size_t)B * outH * outW;
     // scalars: label sum 0, min +inf, max -inf, loss 0, l2 0
@@ -463,9 +467,11 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                g_loss(stream, npix, logits, y_dev, cfg, (double)npix, scalars, backward ? dlogits : nullptr, prob, gscale));
     }
     if (backward) {
+        cur_op = nullptr;
         DN_TRY(ig_begin_backward(this));
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             Op& o = ops[i];
+            cur_op = &o.name;
             switch (o.type) {
                 case OP_HEAD: {
                     if (head_done) break;
@@ -548,6 +554,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
 }
 
 int Model::optimizer_step(float lr) {
+    cur_op = nullptr;
     float gscale = 1.0f;
     if (comm && !dry) {
         // one all-reduce over [gradients ..., loss]: MirroredStrategy's cross-replica sum (engine.py:262) [TF-2.6]

@@ -22,6 +22,7 @@ ap.add_argument('--size', type=int, default=512)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--generic', action='store_true')
 ap.add_argument('--dtype', default='f32')
+ap.add_argument('--layers', action='store_true', help='one row per kernel@layer')
 a = ap.parse_args()
 c = CONFIGS[a.config]
 B = a.batch or c['B']
@@ -40,15 +41,15 @@ for _ in range(a.steps):
     m.train_step_dev(xb, yb, B, 1e-3, cfg)
 ms = m.timer_stop()
 print('%s B=%d %dx%d: %.3f ms/step un-instrumented -> %.1f slices/s' % (a.config, B, a.size, a.size, ms / a.steps, B * a.steps / ms * 1e3))
-m.profile_enable(1)
+m.profile_enable(3 if a.layers else 1)
 for _ in range(a.steps):
     m.train_step_dev(xb, yb, B, 1e-3, cfg)
 m.sync()
 rows = sorted(m.profile(), key=lambda r: -r[2])
 tot = sum(r[2] for r in rows)
-print('%-28s %8s %10s %10s %9s %9s' % ('kernel', 'launches', 'us/launch', 'us/step', 'GB/s', 'GFLOP/s'))
+print('%-44s %8s %10s %10s %9s %9s' % ('kernel', 'launches', 'us/launch', 'us/step', 'GB/s', 'GFLOP/s'))
 for name, n, tms, by, fl in rows:
     us = tms / n * 1e3
-    print('%-28s %8d %10.2f %10.1f %9.1f %9.1f' % (name, n / a.steps, us, tms / a.steps * 1e3, by / us / 1e3, fl / us / 1e3))
+    print('%-44s %8d %10.2f %10.1f %9.1f %9.1f' % (name, n / a.steps, us, tms / a.steps * 1e3, by / us / 1e3, fl / us / 1e3))
 print('sum of kernels: %.1f us/step' % (tot / a.steps * 1e3))
 print('final loss', m.last_step_out().loss)
