@@ -231,6 +231,135 @@ __global__ __launch_bounds__(256) void k_ig_wgrad(WgArgs p) {
 }
 
 
+// weight gradient, second generation: block tile = 16*MW input channels x 16*NN output channels x 9 taps, one persistent
+// block per CU.  The four waves split the input channels MW ways and the pixels (K) 4/MW ways; the pixel tile grows when
+// the channel tile is small so that a tile always carries ~288*NN MFMAs per wave and ~20 KB of staging per thread-round;
+// X and dY are read once per (ci block, co block) pair; the next tile's global loads (raw buffer loads: out-of-image
+// pixels come back as zeros without branches) are issued into registers before a tile's MFMAs and written to LDS after
+// them; the 13 LDS operand words of K-step s+1 are loaded before the 36 MFMAs of step s.
+constexpr unsigned WG_FLAGS = 0x00020000u, WG_OOB = 0x80000000u;
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MW, int NN>
+__global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
+    constexpr int CIT = 16 * MW, COT = 16 * NN, WK = 4 / MW;
+    constexpr int TM = (4 / MW) < (4 / NN) ? (4 / MW) : (4 / NN);
+    constexpr int TYW = 8 * TM, PW = TX + 2, PPATCH = (TYW + 2) * PW, NPX = TYW * TX;
+    constexpr int XS = CIT + (CIT == 16 ? 0 : 16), GS = COT + (COT == 16 ? 0 : 16);   // row strides = 16 (mod 32) banks
+    constexpr int XQ = CIT / 4, GQ = COT / 4;                                           // float4 per pixel
+    constexpr int XU = (PPATCH * XQ + 255) / 256, GU = NPX * GQ / 256;
+    constexpr int NKS = NPX / 4 / WK;                                                   // K-steps per wave per tile
+    __shared__ __attribute__((aligned(16))) float x_lds[PPATCH * XS + 16];
+    __shared__ __attribute__((aligned(16))) float g_lds[NPX * GS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int wm = wave % MW, wk = wave / MW;
+    const int c0 = blockIdx.y * CIT, co0 = blockIdx.z * COT;
+    const bool do_bias = p.dbias && blockIdx.y == 0 && wm == 0;
+    const int tiles_y = (p.H + TYW - 1) / TYW;
+    const int ntiles = p.tiles_x * tiles_y * p.B;
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(npix * p.cs * 4), WG_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (unsigned)(npix * p.cout * 4), WG_FLAGS);
+
+    f32x4 acc[9][NN], accb[NN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NN; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging geometry: X element u = patch pixel (tid + 256u) / XQ, float4 (tid + 256u) % XQ; dY likewise with GQ
+    wg_u32x4 xr[XU], gr[GU];
+    auto issue = [&](int tile) {               // tile >= ntiles: stage nothing (every offset out of range)
+        const unsigned oob = tile < ntiles ? 0u : WG_OOB;
+        tile = tile < ntiles ? tile : 0;
+        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % tiles_y, b = tile / (p.tiles_x * tiles_y);
+        const int x0 = bx * TX, y0 = by * TYW;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 256 * u, px = i / XQ, c4 = i % XQ;
+            const int ly = px / PW, lx = px - ly * PW;
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            const bool ok = px < PPATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = (ok ? (unsigned)(((((b * p.H + iy) * p.W + ix) * p.cs) + c0 + 4 * c4) * 4) : WG_OOB) | oob;
+            xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 256 * u, px = i / GQ, n4 = i % GQ;
+            const int ly = px / TX, lx = px - ly * TX;
+            const int iy = y0 + ly, ix = x0 + lx;
+            const bool ok = iy < p.H && ix < p.W;
+            const unsigned off = (ok ? (unsigned)(((((b * p.H + iy) * p.W + ix) * p.cout) + co0 + 4 * n4) * 4) : WG_OOB) | oob;
+            gr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsg, off, 0, 0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 256 * u, px = i / XQ, c4 = i % XQ;
+            // lanes past the patch (last element only) write into the 16-float dump row behind it
+            *reinterpret_cast<wg_u32x4*>(x_lds + (px < PPATCH ? px * XS + 4 * c4 : PPATCH * XS + 4 * (c4 & 3))) = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 256 * u, px = i / GQ, n4 = i % GQ;
+            *reinterpret_cast<wg_u32x4*>(g_lds + px * GS + 4 * n4) = gr[u];
+        }
+    };
+    // operand words of K-step ks of this wave (4 pixels: tile row ks / 4, pixels 4 (ks % 4) ..)
+    auto load_step = [&](int s, float (&av)[9], float (&bv)[NN]) {
+        const int ks = wk + WK * s, row = ks >> 2, px0 = (ks & 3) * 4;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) bv[j] = g_lds[(row * TX + px0 + q) * GS + 16 * j + m16];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) av[t] = x_lds[((row + t / 3) * PW + px0 + q + t % 3) * XS + 16 * wm + m16];
+    };
+    auto mfma_step = [&](const float (&av)[9], const float (&bv)[NN]) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[j], acc[t][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < NN; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bv[j], accb[j], 0, 0, 0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+#pragma unroll 1
+    for (; tile < ntiles; tile += p.psplit) {
+        lds_barrier();              // the previous tile's operand reads are complete
+        commit();
+        issue(tile + p.psplit);
+        lds_barrier();
+        float a0[9], b0[NN], a1[9], b1[NN];
+        load_step(0, a0, b0);
+#pragma unroll 1
+        for (int s = 0; s < NKS; s += 2) {
+            load_step(s + 1, a1, b1);
+            mfma_step(a0, b0);
+            load_step(s + 2 < NKS ? s + 2 : 0, a0, b0);      // past the last step: a harmless reload
+            mfma_step(a1, b1);
+        }
+    }
+    // D[ci = 16 wm + 4q + i][co = 16j + m16]; the WK pixel-split waves add their partial sums like other blocks do
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(p.dw + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
+    if (do_bias && q == 0) {
+#pragma unroll
+        for (int j = 0; j < NN; ++j) atomicAdd(p.dbias + co0 + 16 * j + m16, accb[j][0]);     // row 0 of the all-ones A
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ transposed conv 2x2/2
 // Conv2DTranspose(k = s = 2) is four independent 1x1 GEMMs, one per output parity (a, e): out[2i+a][2j+e] = W[a][e] . in[i][j].
 // Kernel layout [a][e][Cout][Cin].  M = 128 consecutive input pixels per block (32 per wave).
@@ -1544,6 +1673,21 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             w.psplit = ps < 1 ? 1 : ps;
             LAUNCH(m, "igb_wgrad64", bb, ff,
                    hipLaunchKernelGGL(igb::k_igb_wgrad64, dim3(w.psplit, w.cs / 64, CO / 64), dim3(256), 0, m->stream, w));
+        } else if (!use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (w.cs > CO ? w.cs : CO) * 4.0 < 2.0e9 &&
+                   !getenv("DNNCA_WGRAD1")) {
+            const int mw = w.cs % 64 == 0 ? 4 : (w.cs % 32 == 0 ? 2 : 1);
+            const int tm = (4 / mw) < (4 / nn) ? (4 / mw) : (4 / nn);
+            const int nt2 = tiles_x * ((o.out.d.H + 8 * tm - 1) / (8 * tm)) * B;
+            const int combos2 = (w.cs / (16 * mw)) * (CO / (16 * nn));
+            int ps = (256 + combos2 - 1) / combos2;
+            if (ps > nt2) ps = nt2;
+            w.psplit = ps < 1 ? 1 : ps;
+            dim3 g2(w.psplit, w.cs / (16 * mw), CO / (16 * nn));
+#define WG2(MWv, NNv) LAUNCH(m, "ig_wgrad2", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad2<MWv, NNv>), g2, dim3(256), 0, m->stream, w))
+            if (mw == 4) { if (nn == 4) WG2(4, 4); else if (nn == 2) WG2(4, 2); else WG2(4, 1); }
+            else if (mw == 2) { if (nn == 4) WG2(2, 4); else if (nn == 2) WG2(2, 2); else WG2(2, 1); }
+            else { if (nn == 4) WG2(1, 4); else if (nn == 2) WG2(1, 2); else WG2(1, 1); }
+#undef WG2
         } else if (use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
         else if (use_bf16(m, o) && nn == 2) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<2>), grid, dim3(256), 0, m->stream, w));
         else if (nn == 4) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<4>), grid, dim3(256), 0, m->stream, w));
