@@ -156,8 +156,8 @@ def _to_bf16(a):
     return u.astype(np.uint32).view(np.float32).astype(np.float64)
 
 
-@pytest.mark.parametrize('f0', [32, 64])
-def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch, f0):
+@pytest.mark.parametrize('f0,S', [(32, 32), (64, 32), (64, 24)])
+def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch, f0, S):
     """dtype bf16: the implicit-GEMM kernels round their operands (activations, gradients, weights) to bf16 while staging
     and accumulate in fp32.  The oracle is made to do exactly that (operands of every 3x3 conv rounded to bf16, float64
     accumulation), so the comparison isolates the kernels' indexing from bf16 noise: what remains is fp32 accumulation
@@ -197,7 +197,7 @@ def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch, f0):
     spec = O.ModelSpec('unet', 32, **opts)
     params = Hp.perturbed_params(spec, np.float64)
     rng = np.random.default_rng(3)
-    B, S = 2, 32
+    B = 2           # S = 24: no tile size divides the image (16x16 / 8x16 pixel tiles, 128-pixel runs)
     x = rng.random((B, S, S, 32)).astype(np.float32)
     _, y = O.synthetic_batch(B, S, S, 1)
     cfg = dict(weight_mul=3.0)
@@ -208,7 +208,10 @@ def test_bf16_kernels_against_bf16_emulating_oracle(gpu, monkeypatch, f0):
     # the device rounds fp32 activations, the emulation float64 ones: values within 1e-7 of a bf16 rounding boundary can
     # land on different sides, so the agreement is a fraction of the bf16 noise (2e-3 on these logits), not fp32-exact
     noise = float(np.abs(logits - O.forward(spec, params, x.astype(np.float64))[0]).max()) if False else 2e-3
-    assert np.abs(lg - logits).max() <= 0.5 * noise, np.abs(lg - logits).max()
+    dl = np.abs(lg - logits)
+    # flipped roundings upstream reach every logit a little: within the bf16 noise at worst, a small fraction of it typically
+    # (an indexing error shows up as O(0.1))
+    assert dl.max() <= noise and np.median(dl) <= 0.25 * noise, (dl.max(), np.median(dl))
     out = m.train_step(x, y, 0.0, m.loss_cfg(**cfg))
     assert abs(out.loss - loss) <= 1e-3 * max(1.0, abs(loss))
     g, gref = m.get_grads().astype(np.float64), O.flatten(spec, grads)
@@ -298,13 +301,15 @@ def test_cli_train_then_evaluate_on_tfrecords(gpu, tmp_path):
 @pytest.mark.parametrize('arch, C, opts', [
     ('unet', 1, dict(n_filters_first=3, n_downsample=3, bn=False)),                      # configs/unet.yaml + overlays
     ('mulmo', 2, dict(n_filters_first=16, n_downsample=2, bn=True)),                      # dense-channel kernels
+    ('unet', 1, dict(n_filters_first=16, n_downsample=1, bn=True, rate=4)),               # rate 4: 16 -> 64 channel convs, 4x4 pool / transposed conv
 ])
 def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
     """Tuned kernels on a non-square image (48 x 80: partial tiles in both directions) with the LeakyReLU and L2-regulariser
     overlays of the reference (configs/additionals/leakyReLU.yaml, kernel_regularizer.yaml) against the float64 oracle."""
     full = dict(rate=2, kernel_size=3, conv_stride=1, padding='same',
                 activation={'class_name': 'LeakyReLU', 'config': {'alpha': 0.3}},
-                kernel_regularizer={'class_name': 'L2', 'config': {'l2': 0.01}}, **opts)
+                kernel_regularizer={'class_name': 'L2', 'config': {'l2': 0.01}})
+    full.update(opts)
     spec = O.ModelSpec(arch, C, **full)
     params = Hp.perturbed_params(spec, np.float64)
     B, H, W = 3, 48, 80
