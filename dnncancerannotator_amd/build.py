@@ -30,7 +30,7 @@ def build_library(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _newer([s] + headers, o):
-            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + (['-DDNNCA_TUNING'] if os.environ.get('DNNCA_TUNING') else []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -360,6 +360,212 @@ __global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
     }
 }
 
+// forward / data gradient, fp32, persistent and software-pipelined: the f32 twin of igb::k_igb_conv3 (see there for the
+// scheme).  Block tile 16 x 16 pixels x 16*NN channels, K chunks of 16 input channels; per item 576*NN/4... MFMAs per
+// wave (4 M-tiles x NN N-tiles x 9 taps x 4 K-steps of v_mfma_f32_16x16x4_f32), walked dx-major: one step = (dx, K-step)
+// loads 6 A words that serve the three dy taps, operand words of step s+1 are loaded before the MFMAs of step s.
+constexpr int F3T = 16, F3PATCH = (F3T + 2) * (F3T + 2);       // tile edge, staged patch pixels
+constexpr int F3AS = CK + 4;                                    // A row stride (floats)
+
+template <int NN, int MODE>
+__global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
+    constexpr int COT = 16 * NN, BS = COT + 16;                 // B row stride (floats): 16 (mod 32) banks
+    constexpr int ABUF = F3PATCH * F3AS, BBUF = 9 * CK * BS;
+    constexpr int OSTR = COT + 4;
+    constexpr int BUF = (ABUF + BBUF + 16) > (256 * OSTR) ? (ABUF + BBUF + 16) : (256 * OSTR);   // floats per LDS buffer
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
+    const int nco = nout / COT, ntiles = p.tiles_x * p.tiles_y * p.B, nunits = ntiles * nco;
+    const int nchunks = kin / CK;
+    const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+    const int my_units = (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nitems = my_units * nchunks;
+    if (nitems <= 0) return;
+
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * 4), nbytes1 = (unsigned)(npix * p.c_src1 * 4);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((size_t)9 * nout * kin * 4), WG_FLAGS);
+
+    struct Unit { int b, y0, x0, co0; };
+    auto unit_of = [&](int k) {
+        const int id = blockIdx.x + k * gridDim.x;
+        int tile, cot;
+        if (xcd_map) {
+            const int xcd = id & 7, j = id >> 3;
+            cot = j % nco;
+            tile = (j / nco) * 8 + xcd;
+        } else {
+            cot = id % nco;
+            tile = id / nco;
+        }
+        Unit u;
+        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y;
+        u.b = tile / (p.tiles_x * p.tiles_y);
+        u.x0 = bx * F3T; u.y0 = by * F3T; u.co0 = cot * COT;
+        return u;
+    };
+
+    // staging geometry: A element v = patch pixel (tid >> 2) + 64 v, float4 tid & 3; B element v = slab row
+    // (tid + 256 v) / (4 NN) (= tap * 16 + k), float4 (tid + 256 v) % (4 NN)
+    constexpr int AU = (F3PATCH * 4 + 255) / 256, BU = (9 * CK * 4 * NN + 255) / 256;
+    const int c4 = tid & 3;
+    int a_ly[AU], a_lx[AU];
+#pragma unroll
+    for (int v = 0; v < AU; ++v) {
+        const int px = (tid >> 2) + 64 * v;
+        a_ly[v] = px / (F3T + 2);
+        a_lx[v] = px - a_ly[v] * (F3T + 2);
+        if (px >= F3PATCH) a_ly[v] = -4096;
+    }
+    wg_u32x4 ar[AU], br[BU];
+    struct Stage { int b, y0, x0, co0, cc, cs, c0; unsigned oob; __amdgpu_buffer_rsrc_t rs; };
+    auto stage_of = [&](int item) {
+        const int valid = item < nitems;
+        item = valid ? item : 0;
+        const int k = item / nchunks;
+        const Unit u = unit_of(k);
+        Stage st;
+        st.b = u.b; st.y0 = u.y0; st.x0 = u.x0; st.co0 = u.co0;
+        st.cc = (item - k * nchunks) * CK;
+        const bool second = st.cc >= p.c_src0;
+        st.cs = second ? p.c_src1 : p.c_src0;
+        st.c0 = second ? st.cc - p.c_src0 : st.cc;
+        st.oob = valid ? 0u : WG_OOB;
+        st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.src[1] : p.src[0]), 0, second ? nbytes1 : nbytes0, WG_FLAGS);
+        return st;
+    };
+    auto issue_a = [&](const Stage& st, int v) {
+        const int iy = st.y0 - 1 + a_ly[v], ix = st.x0 - 1 + a_lx[v];
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned off = (ok ? (unsigned)(((((st.b * p.H + iy) * p.W + ix) * st.cs) + st.c0 + 4 * c4) * 4) : WG_OOB) | st.oob;
+        ar[v] = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
+    };
+    auto issue_b = [&](const Stage& st, int v) {
+        const int i = tid + 256 * v, n4 = i % (4 * NN), r = i / (4 * NN);
+        const bool ok = r < 9 * CK;
+        const unsigned off = (ok ? (unsigned)(((((r >> 4) * kin + st.cc + (r & 15)) * nout) + st.co0 + 4 * n4) * 4) : WG_OOB) | st.oob;
+        br[v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0);
+    };
+    auto commit_a = [&](float* buf, int v) {
+        const int px = (tid >> 2) + 64 * v;
+        *reinterpret_cast<wg_u32x4*>(buf + (px < F3PATCH ? px * F3AS : ABUF + BBUF) + 4 * c4) = ar[v];     // idle lanes: dump row
+    };
+    auto commit_b = [&](float* buf, int v) {
+        const int i = tid + 256 * v, n4 = i % (4 * NN), r = i / (4 * NN);
+        *reinterpret_cast<wg_u32x4*>(buf + (r < 9 * CK ? ABUF + r * BS + 4 * n4 : ABUF + BBUF + 4 * (n4 & 3))) = br[v];
+    };
+
+    f32x4 acc[4][NN];
+    {
+        const Stage s0 = stage_of(0);
+#pragma unroll
+        for (int v = 0; v < AU; ++v) issue_a(s0, v);
+#pragma unroll
+        for (int v = 0; v < BU; ++v) issue_b(s0, v);
+#pragma unroll
+        for (int v = 0; v < AU; ++v) commit_a(lds, v);
+#pragma unroll
+        for (int v = 0; v < BU; ++v) commit_b(lds, v);
+        const Stage s1 = stage_of(1);
+#pragma unroll
+        for (int v = 0; v < AU; ++v) issue_a(s1, v);
+#pragma unroll
+        for (int v = 0; v < BU; ++v) issue_b(s1, v);
+    }
+    lds_barrier();
+#pragma unroll 1
+    for (int it = 0; it < nitems; ++it) {
+        float* buf = lds + (it & 1) * BUF;
+        float* other = lds + ((it & 1) ^ 1) * BUF;
+        const int k = it / nchunks, chunk = it - k * nchunks;
+        const Stage nx = stage_of(it + 2);
+        if (chunk == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* a_lds = buf + ((4 * wave) * (F3T + 2) + m16) * F3AS + q;
+        const float* b_lds = buf + ABUF + q * BS + m16;
+        // step s = (dx = s / 4, K-step k4 = s % 4): 6 A words (rows 0..5) + 3 x NN B words (dy = 0..2)
+        float fa[2][6], fb[2][3][NN];
+        auto load_step = [&](int s, float (&a)[6], float (&bw)[3][NN]) {
+            const int g = s >> 2, k4 = s & 3;
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) a[rr] = a_lds[(rr * (F3T + 2) + g) * F3AS + 4 * k4];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int j = 0; j < NN; ++j) bw[dy][j] = b_lds[((dy * 3 + g) * CK + 4 * k4) * BS + 16 * j];
+        };
+        load_step(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            if (s + 1 < 12) load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+            if (s >= 1 && s <= 9) {                     // staging slice s-1 (nine slices: A elements 0..5, B elements 0..8)
+                const int v = s - 1;
+                if (v < AU) { commit_a(other, v); issue_a(nx, v); }
+                if (v < BU) { commit_b(other, v); issue_b(nx, v); }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j)
+                        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s & 1][r + dy], fb[s & 1][dy][j], acc[r][j], 0, 0, 0);
+        }
+        lds_barrier();
+        if (chunk == nchunks - 1) {
+            const Unit u = unit_of(k);
+            float* o_lds = buf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < NN; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o_lds[((4 * wave + r) * F3T + 4 * q + i) * OSTR + 16 * j + m16] = acc[r][j][i];
+            lds_barrier();
+            const int which = u.co0 >= p.n_dst0;
+            const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? u.co0 - p.n_dst0 : u.co0;
+            float* dst = p.dst[which];
+            constexpr int TPP = 4 * NN, PPP = 256 / TPP;          // threads per pixel, pixels per pass
+            const int e4 = tid % TPP, prow = tid / TPP;
+            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 0 && p.bias) bias = *reinterpret_cast<const float4*>(p.bias + u.co0 + 4 * e4);
+#pragma unroll 4
+            for (int v = 0; v < TPP; ++v) {
+                const int px = prow + PPP * v, ly = px >> 4, lx = px & 15;
+                const int y = u.y0 + ly, x = u.x0 + lx;
+                if (y >= p.H || x >= p.W) continue;
+                float4 val = *reinterpret_cast<const float4*>(o_lds + px * OSTR + 4 * e4);
+                const size_t o = (((size_t)u.b * p.H + y) * p.W + x) * cw + cl + 4 * e4;
+                if (MODE == 0) {
+                    val.x += bias.x; val.y += bias.y; val.z += bias.z; val.w += bias.w;
+                    if (p.alpha >= 0.f) {
+                        val.x = val.x > 0.f ? val.x : p.alpha * val.x; val.y = val.y > 0.f ? val.y : p.alpha * val.y;
+                        val.z = val.z > 0.f ? val.z : p.alpha * val.z; val.w = val.w > 0.f ? val.w : p.alpha * val.w;
+                    }
+                } else {
+                    if (p.acc[which]) {
+                        const float4 t = *reinterpret_cast<const float4*>(dst + o);
+                        val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w;
+                    }
+                    if (p.mask[which]) {
+                        const float4 mk = *reinterpret_cast<const float4*>(p.mask[which] + o);
+                        val.x *= mk.x > 0.f ? 1.0f : p.alpha; val.y *= mk.y > 0.f ? 1.0f : p.alpha;
+                        val.z *= mk.z > 0.f ? 1.0f : p.alpha; val.w *= mk.w > 0.f ? 1.0f : p.alpha;
+                    }
+                }
+                *reinterpret_cast<float4*>(dst + o) = val;
+            }
+            lds_barrier();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ transposed conv 2x2/2
 // Conv2DTranspose(k = s = 2) is four independent 1x1 GEMMs, one per output parity (a, e): out[2i+a][2j+e] = W[a][e] . in[i][j].
 // Kernel layout [a][e][Cout][Cin].  M = 128 consecutive input pixels per block (32 per wave).
@@ -1585,6 +1791,23 @@ int ig_begin_backward(Model* m) {
 
 template <int MODE>
 static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* name, double bytes, double flops) {
+    {   // pipelined persistent kernel: channel tile 16 nn3 must divide both destinations; 32-bit byte offsets
+        const int d1 = a.n_dst1 ? a.n_dst1 : 64;
+        const int nn3 = (a.n_dst0 % 64 == 0 && d1 % 64 == 0) ? 4 : ((a.n_dst0 % 32 == 0 && d1 % 32 == 0) ? 2 : 1);
+        const int cmax = a.c_src0 > a.c_src1 ? a.c_src0 : a.c_src1;
+        static const bool use_v1 = getenv("DNNCA_IGCONV1") != nullptr;
+        if (!use_v1 && (double)a.B * a.H * a.W * cmax * 4.0 < 2.0e9 && 9.0 * cout * (a.c_src0 + a.c_src1) * 4.0 < 2.0e9) {
+            ig::ConvArgs a2 = a;
+            a2.tiles_x = (a.W + ig::F3T - 1) / ig::F3T;
+            a2.tiles_y = (a.H + ig::F3T - 1) / ig::F3T;
+            const unsigned units = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / (16 * nn3)));
+            const unsigned g = units < 256u ? units : 256u;
+            if (nn3 == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<4, MODE>), dim3(g), dim3(256), 0, m->stream, a2));
+            else if (nn3 == 2) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<2, MODE>), dim3(g), dim3(256), 0, m->stream, a2));
+            else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<1, MODE>), dim3(g), dim3(256), 0, m->stream, a2));
+            return;
+        }
+    }
     const int nn = pick_nn(cout);
     dim3 grid(a.tiles_x * a.tiles_y * a.B, cout / (16 * nn));
     if (nn == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv<4, MODE>), grid, dim3(256), 0, m->stream, a));

@@ -254,10 +254,18 @@ __device__ __forceinline__ unsigned long long stamp() {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
+// The stamps and the phase-skipping switches are compiled in only for tuning builds (DNNCA_TUNING=1 python -m
+// dnncancerannotator_amd.build): in the shipped kernel they would sit as branches in the per-tile loop.
+#ifdef DNNCA_TUNING
 #define STAMP(i)                                                                                        \
     do {                                                                                                \
         if (p.stamps && wave == 0 && lane == 0 && it < 4) p.stamps[((size_t)blockIdx.x * 4 + it) * 8 + (i)] = stamp(); \
     } while (0)
+#define DBG_FLAGS(p) ((p).dbg)
+#else
+#define STAMP(i) do { } while (0)
+#define DBG_FLAGS(p) 0
+#endif
 
 // ================================================================================================ backward (fused)
 struct BwdArgs {
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
 
         STAMP(2);
         // ---- data gradient: conv of dz with the flipped kernel; M-tiles of 16 groups x Gd pixels
-        if (DGRAD && !(p.dbg & 1)) {
+        if (DGRAD && !(DBG_FLAGS(p) & 1)) {
             // M-tiles of this wave: t = wave + 4j, j < MTX*TH/4; NCH of them are processed with interleaved MFMA chains
             constexpr int PERW = Wc::MTX * TH / NW;
             constexpr int NCH = PERW >= 4 ? 4 : PERW;
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
         STAMP(3);
         // ---- weight gradient: K = pixel groups (4 per MFMA); every wave takes rows ty = wave, wave + 4
 #pragma unroll 1
-        for (int ty = (p.dbg & 2) ? TH : wave; ty < TH; ty += NW) {
+        for (int ty = (DBG_FLAGS(p) & 2) ? TH : wave; ty < TH; ty += NW) {
             const int goff = n < Nw ? GOFF + (ty + 1) * LSg + TGg::HL + q * Nw + n : CST0;
             const int gstep = n < Nw ? 4 * Nw : 0;
             int aoffs[NSRC][MT];
