@@ -35,8 +35,9 @@ bool ig_conv_supported(const Model* m, const Op& o);
 int ig_prepare(Model* m);
 int ig_begin_backward(Model* m);
 void ig_release(Model* m);
-bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops);
+bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);   // bn_next: BatchNorm of the output whose statistics may ride in the epilogue
 bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
+bool bn_scratch(Model* m, size_t bytes, void** out);       // the model's BN partials table, grown on demand
 bool ig_tconv_supported(const Model* m, const Op& o);
 bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops);
 bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);   // decides maskA/maskB/premasked for every op (static per model)

@@ -24,6 +24,38 @@ constexpr int PATCH = (TY + 2) * (TX + 2);
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- BatchNorm statistics in the epilogue of the persistent forward conv kernels (see ConvArgs::bn_part).  The macros
+// expand inside the epilogue, where `val` is the float4 just stored for pixel (y, x) / channels 4 e4 .. (cw channels in
+// all, this unit's first channel cl), `prow` / `PPP` / `COT` the thread -> (pixel row, channel quad) map.
+// (The backward sums of a BatchNorm were tried in the consuming conv's data-gradient epilogue too: the extra read of the
+// normalised input there cost more than the reduction pass it replaced -- 2.1 -> 3.2 ms of dgrad against 0.7 ms saved.)
+#define BN_EPI_DECL                                                                                                     \
+    const bool bn_on = MODE == 0 && p.bn_part != nullptr;                                                                \
+    float bn_s[4] = {0.f, 0.f, 0.f, 0.f}, bn_q[4] = {0.f, 0.f, 0.f, 0.f};
+#define BN_EPI_ACC                                                                                                      \
+    if (bn_on) {                                                                                                         \
+        bn_s[0] += val.x; bn_s[1] += val.y; bn_s[2] += val.z; bn_s[3] += val.w;                                          \
+        bn_q[0] = fmaf(val.x, val.x, bn_q[0]); bn_q[1] = fmaf(val.y, val.y, bn_q[1]);                                    \
+        bn_q[2] = fmaf(val.z, val.z, bn_q[2]); bn_q[3] = fmaf(val.w, val.w, bn_q[3]);                                    \
+    }
+// partial row of this unit: [tile][2 cw]: first half sums, second half sums of squares
+#define BN_EPI_TAIL                                                                                                     \
+    if (bn_on) {                                                                                                         \
+        lds_barrier();                      /* every thread is done reading the output image */                        \
+        float* red = reinterpret_cast<float*>(buf);                                                                      \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                  \
+            red[prow * (2 * COT) + 4 * e4 + c] = bn_s[c];                                                                \
+            red[prow * (2 * COT) + COT + 4 * e4 + c] = bn_q[c];                                                          \
+        }                                                                                                                \
+        lds_barrier();                                                                                                   \
+        if (tid < 2 * COT) {                                                                                             \
+            float a = 0.f;                                                                                               \
+            for (int r = 0; r < PPP; ++r) a += red[r * (2 * COT) + tid];                                                 \
+            const int half = tid >= COT, c = half ? tid - COT : tid;                                                     \
+            p.bn_part[(size_t)u.tile * (2 * cw) + half * cw + cl + c] = a;                                               \
+        }                                                                                                                \
+    }
+
 struct ConvArgs {
     const float* src[2];     // dense NHWC sources; chunk cc comes from src[cc >= c_src0]
     int c_src0, c_src1;      // channels of the two sources (c_src1 = 0: one source)
@@ -36,6 +68,8 @@ struct ConvArgs {
     int B, H, W;
     int tiles_x, tiles_y;
     float alpha;             // forward: activation slope (<0 none); data gradient: slope of the masked activation
+    // forward: batch statistics of the BatchNorm behind this conv ride in the epilogue of the persistent kernels:
+    float* bn_part;          // [tile][2 * Cout] float partials (sum, sum of squares per channel); nullptr: none
 };
 
 // MODE 0 forward, MODE 1 data gradient
@@ -388,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
     const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * 4), nbytes1 = (unsigned)(npix * p.c_src1 * 4);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((size_t)9 * nout * kin * 4), WG_FLAGS);
 
-    struct Unit { int b, y0, x0, co0; };
+    struct Unit { int b, y0, x0, co0, tile; };
     auto unit_of = [&](int k) {
         const int id = blockIdx.x + k * gridDim.x;
         int tile, cot;
@@ -403,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
         Unit u;
         const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y;
         u.b = tile / (p.tiles_x * p.tiles_y);
-        u.x0 = bx * F3T; u.y0 = by * F3T; u.co0 = cot * COT;
+        u.x0 = bx * F3T; u.y0 = by * F3T; u.co0 = cot * COT; u.tile = tile;
         return u;
     };
 
@@ -535,6 +569,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
             const int e4 = tid % TPP, prow = tid / TPP;
             float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == 0 && p.bias) bias = *reinterpret_cast<const float4*>(p.bias + u.co0 + 4 * e4);
+            BN_EPI_DECL
 #pragma unroll 4
             for (int v = 0; v < TPP; ++v) {
                 const int px = prow + PPP * v, ly = px >> 4, lx = px & 15;
@@ -560,7 +595,9 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
                     }
                 }
                 *reinterpret_cast<float4*>(dst + o) = val;
+                BN_EPI_ACC
             }
+            BN_EPI_TAIL
             lds_barrier();
         }
     }
@@ -1145,7 +1182,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * 4), nbytes1 = (unsigned)(npix * p.c_src1 * 4);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)w16, 0, (unsigned)((size_t)9 * nout * kin * 2), BUF_FLAGS);
 
-    struct Unit { int b, y0, x0, co0; };
+    struct Unit { int b, y0, x0, co0, tile; };
     auto unit_of = [&](int k) {
         const int id = blockIdx.x + k * gridDim.x;
         int tile, cot;
@@ -1160,7 +1197,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         Unit u;
         const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y;
         u.b = tile / (p.tiles_x * p.tiles_y);
-        u.x0 = bx * T2; u.y0 = by * T2; u.co0 = cot * 64;
+        u.x0 = bx * T2; u.y0 = by * T2; u.co0 = cot * 64; u.tile = tile;
         return u;
     };
 
@@ -1303,8 +1340,11 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
             const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? u.co0 - p.n_dst0 : u.co0;
             float* dst = p.dst[which];
             const int e4 = tid & 15;
+            constexpr int COT = 64, PPP = 16;
+            const int prow = tid >> 4;
             float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == 0 && p.bias) bias = *reinterpret_cast<const float4*>(p.bias + u.co0 + 4 * e4);
+            BN_EPI_DECL
 #pragma unroll 4
             for (int v = 0; v < 16; ++v) {
                 const int px = (tid >> 4) + 16 * v, ly = px >> 4, lx = px & 15;
@@ -1330,7 +1370,9 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
                     }
                 }
                 *reinterpret_cast<float4*>(dst + o) = val;
+                BN_EPI_ACC
             }
+            BN_EPI_TAIL
             lds_barrier();          // the next item's staging writes land in this buffer
         }
     }
@@ -1789,14 +1831,22 @@ int ig_begin_backward(Model* m) {
     return DNNCA_OK;
 }
 
+// will launch_ig / launch_igb take the persistent kernel (k_ig_conv3 / k_igb_conv3) for these arguments?
+static bool conv3_path(const ig::ConvArgs& a, int cout, bool bf16) {
+    if (bf16) return cout % 64 == 0 && a.c_src0 % 32 == 0 && a.c_src1 % 32 == 0 && a.n_dst0 % 64 == 0 && !getenv("DNNCA_CONV2");
+    const int cmax = a.c_src0 > a.c_src1 ? a.c_src0 : a.c_src1;
+    return !getenv("DNNCA_IGCONV1") && (double)a.B * a.H * a.W * cmax * 4.0 < 2.0e9 && 9.0 * cout * (a.c_src0 + a.c_src1) * 4.0 < 2.0e9;
+}
+static int conv3_rows(const ig::ConvArgs& a) { return ((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B; }     // 16 x 16 pixel tiles
+
 template <int MODE>
 static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* name, double bytes, double flops) {
     {   // pipelined persistent kernel: channel tile 16 nn3 must divide both destinations; 32-bit byte offsets
         const int d1 = a.n_dst1 ? a.n_dst1 : 64;
         const int nn3 = (a.n_dst0 % 64 == 0 && d1 % 64 == 0) ? 4 : ((a.n_dst0 % 32 == 0 && d1 % 32 == 0) ? 2 : 1);
         const int cmax = a.c_src0 > a.c_src1 ? a.c_src0 : a.c_src1;
-        static const bool use_v1 = getenv("DNNCA_IGCONV1") != nullptr;
-        if (!use_v1 && (double)a.B * a.H * a.W * cmax * 4.0 < 2.0e9 && 9.0 * cout * (a.c_src0 + a.c_src1) * 4.0 < 2.0e9) {
+        (void)cmax;
+        if (conv3_path(a, cout, false)) {
             ig::ConvArgs a2 = a;
             a2.tiles_x = (a.W + ig::F3T - 1) / ig::F3T;
             a2.tiles_y = (a.H + ig::F3T - 1) / ig::F3T;
@@ -1824,8 +1874,7 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
         a2.tiles_x = (a.W + igb::T2 - 1) / igb::T2;
         a2.tiles_y = (a.H + igb::T2 - 1) / igb::T2;
         const unsigned nblocks = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / 64));
-        static const bool use_v2 = getenv("DNNCA_CONV2") != nullptr;          // tuning aid: the non-persistent variant
-        if (!use_v2 && a.n_dst0 % 64 == 0) {
+        if (conv3_path(a, cout, true)) {          // DNNCA_CONV2 (tuning aid) selects the non-persistent variant
             const unsigned g = nblocks < 256u ? nblocks : 256u;
             LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE>), dim3(g), dim3(256), 0, m->stream, a2, w16));
             return;
@@ -1838,7 +1887,7 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
     else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv<2, MODE>), grid, dim3(256), 0, m->stream, a, w16));
 }
 
-bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
+bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next) {
     if (!ig_conv_supported(m, o)) return false;
     ig::ConvArgs a{};
     a.src[0] = o.inA.d.p; a.src[1] = o.inB.d.p;
@@ -1850,6 +1899,15 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
     a.tiles_x = (a.W + ig::TX - 1) / ig::TX;
     a.tiles_y = (a.H + ig::TY - 1) / ig::TY;
     a.alpha = o.alpha;
+    if (bn_next && !m->dry && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
+        // the BatchNorm behind this conv takes its batch statistics from the conv's epilogue
+        const int rows = conv3_rows(a);
+        void* part = nullptr;
+        if (bn_scratch(m, (size_t)rows * 2 * o.out.d.C * 4, &part)) {
+            a.bn_part = (float*)part;
+            bn_next->fused_stats_rows = rows;
+        }
+    }
     if (use_bf16(m, o)) {
         IgPlan& pl = g_ig[m];
         launch_igb<0>(m, a, pl.wf + o.w_off, o.out.d.C, "igb_conv_fwd", bytes, flops);

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     }
 
     int it = 0, buf = 0;
+    (void)it;          // read by the tuning build's stamps only
     if (DB && tile < ntiles) {
         tile_commit<CO, TW, NT>(preg, okg, lds4, tid);
 #pragma unroll

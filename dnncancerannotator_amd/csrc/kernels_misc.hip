@@ -562,34 +562,38 @@ __global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float*
     }
 }
 
-// fold of a [nb][2C] partials table: block = 32 channels x 32 row lanes (1024 threads), grid = ceil(C / 32)
-template <typename TP>
-__device__ __forceinline__ void bn_fold(const TP* __restrict__ part, int nb, int C, double& a0, double& a1, double (*red)[32][2]) {
-    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+// fold of a [nb][2C] partials table: block = CPB channels x 1024/CPB row lanes, grid = ceil(C / CPB).  CPB = 32 for the
+// few hundred rows the reduction kernels leave, 8 (more blocks, more rows in flight) for the per-tile rows a conv epilogue
+// leaves (thousands).  The result (two sums per channel) lands in the first CPB threads.
+template <int CPB, typename TP>
+__device__ __forceinline__ void bn_fold(const TP* __restrict__ part, int nb, int C, double& a0, double& a1, double* red) {
+    constexpr int RL = 1024 / CPB;
+    const int cl = threadIdx.x % CPB, r = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
     double s0 = 0.0, s1 = 0.0;
     if (c < C)
-        for (int b = r; b < nb; b += 32) {
+        for (int b = r; b < nb; b += RL) {
             s0 += (double)part[(size_t)b * 2 * C + c];
             s1 += (double)part[(size_t)b * 2 * C + C + c];
         }
-    red[r][cl][0] = s0;
-    red[r][cl][1] = s1;
+    red[(r * CPB + cl) * 2] = s0;
+    red[(r * CPB + cl) * 2 + 1] = s1;
     __syncthreads();
     a0 = 0.0; a1 = 0.0;
     if (r == 0)
-        for (int l = 0; l < 32; ++l) { a0 += red[l][cl][0]; a1 += red[l][cl][1]; }
+        for (int l = 0; l < RL; ++l) { a0 += red[(l * CPB + cl) * 2]; a1 += red[(l * CPB + cl) * 2 + 1]; }
 }
 
 // raw moments -> coefficients (and the moving statistics in training): same contract as g_bn_finalize
-__global__ __launch_bounds__(1024) void k_bn_fold_stats(int C, int nb, double n, const double* __restrict__ part,
+template <int CPB, typename TP>
+__global__ __launch_bounds__(1024) void k_bn_fold_stats(int C, int nb, double n, const TP* __restrict__ part,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ mmean, float* __restrict__ mvar,
                                                         float* __restrict__ coef, float momentum, float eps) {
-    __shared__ double red[32][32][2];
+    __shared__ double red[2048];
     double sum, sumsq;
-    bn_fold(part, nb, C, sum, sumsq, red);
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    bn_fold<CPB>(part, nb, C, sum, sumsq, red);
+    const int c = blockIdx.x * CPB + (int)(threadIdx.x % CPB);
+    if (threadIdx.x >= CPB || c >= C) return;
     const double mean_d = sum / n;
     double var_d = sumsq / n - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
@@ -607,9 +611,9 @@ __global__ __launch_bounds__(1024) void k_bn_fold_stats(int C, int nb, double n,
 
 __global__ __launch_bounds__(1024) void k_bn_fold_bwd(int C, int nb, const float* __restrict__ part, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta) {
-    __shared__ double red[32][32][2];
+    __shared__ double red[2048];
     double g, b;
-    bn_fold(part, nb, C, g, b, red);
+    bn_fold<32>(part, nb, C, g, b, red);
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     if ((threadIdx.x >> 5) != 0 || c >= C) return;
     dgamma[c] += (float)g;
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
 }
 
 // partials table shared by all BN ops of a model (stream-ordered use); grown on demand
-static bool bn_scratch(Model* m, size_t bytes, void** out) {
+bool bn_scratch(Model* m, size_t bytes, void** out) {
     if (bytes > m->bn_part_bytes) {
         void* p = nullptr;
         if (m->alloc(&p, bytes) != DNNCA_OK) return false;
@@ -730,14 +734,25 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
     const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
     const double tb = 4.0 * npix * C;
     if (training) {
-        const unsigned nb = bn_blocks(npix, C);
-        double* part = nullptr;
-        DN_TRYB(bn_scratch(m, (size_t)nb * 2 * C * 8, (void**)&part));
-        LAUNCH(m, "bn_stats", tb, 3 * tb / 4,
-               hipLaunchKernelGGL(k_bn_stats_fast, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, part));
-        LAUNCH(m, "bn_fold_stats", 16.0 * nb * C, 0,
-               hipLaunchKernelGGL(k_bn_fold_stats, dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, (double)npix, part,
-                                  m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off, m->state + o.mv_off, o.coef, momentum, eps));
+        if (o.fused_stats_rows > 0 && !m->dry) {
+            // the producing conv left [rows][2C] float partials in the partials table (its epilogue saw every output value)
+            const int rows = o.fused_stats_rows;
+            o.fused_stats_rows = 0;
+            LAUNCH(m, "bn_fold_stats", 8.0 * rows * C, 0,
+                   hipLaunchKernelGGL((k_bn_fold_stats<8, float>), dim3((C + 7) / 8), dim3(1024), 0, m->stream, C, rows, (double)npix,
+                                      (const float*)m->bn_part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,
+                                      m->state + o.mv_off, o.coef, momentum, eps));
+        } else {
+            const unsigned nb = bn_blocks(npix, C);
+            double* part = nullptr;
+            DN_TRYB(bn_scratch(m, (size_t)nb * 2 * C * 8, (void**)&part));
+            LAUNCH(m, "bn_stats", tb, 3 * tb / 4,
+                   hipLaunchKernelGGL(k_bn_stats_fast, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, part));
+            LAUNCH(m, "bn_fold_stats", 16.0 * nb * C, 0,
+                   hipLaunchKernelGGL((k_bn_fold_stats<32, double>), dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, (double)npix,
+                                      (const double*)part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off, m->state + o.mv_off,
+                                      o.coef, momentum, eps));
+        }
     } else {
         LAUNCH(m, "g_bn_finalize", 0, 0,
                g_bn_finalize(m->stream, C, (double)npix, o.ws, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,

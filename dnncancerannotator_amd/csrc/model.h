@@ -35,6 +35,9 @@ struct Op {
     float mask_alpha = 0.f;
     float* coef = nullptr;               // BN: [scale, shift, mean, inv] x C
     double* ws = nullptr;                // BN: [sum, centred sumsq] x C
+    // BN batch statistics that rode in the producing conv's epilogue this step: rows of float partials waiting in the
+    // model's partials table (0: none)
+    int fused_stats_rows = 0;
 };
 
 struct ParamInfo {

@@ -387,7 +387,9 @@ int Model::forward(const float* x_dev, int B, bool training) {
                     pool_done = pool;
                     break;
                 }
-                if (!generic && (fast_first_conv_fwd(this, B, o, bytes, flops) || ig_conv_fwd(this, B, o, bytes, flops))) break;
+                Op* bn_next = (training && oi + 1 < ops.size() && ops[oi + 1].type == OP_BN && ops[oi + 1].inA.d.p == o.out.d.p &&
+                               fast_bn_supported(this, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
+                if (!generic && (fast_first_conv_fwd(this, B, o, bytes, flops) || ig_conv_fwd(this, B, o, bytes, flops, bn_next))) break;
                 LAUNCH(this, "g_conv_fwd", bytes, flops,
                        g_conv_fwd(stream, B, o.inA.d, o.inB.d, p + o.w_off, p + o.b_off, o.out.d, o.k, o.alpha));
                 break;
