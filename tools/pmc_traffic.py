@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Post-processing of rocprofv3 counter-collection CSVs (one counter per pass, as MI355X_MICROARCH.md's HBM section prescribes).
+
+    python tools/pmc_traffic.py traffic FETCH.csv WRITE.csv > profiles/roofline_traffic.json
+        HBM-side bytes per launch and kernel = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB; on gfx950 FETCH_SIZE
+        tallies 128-byte requests at 64 bytes, hence the factor 2), keyed by the library's launch names.
+    python tools/pmc_traffic.py ratio NUM.csv DEN.csv
+        per-kernel ratio of two counters summed over launches (e.g. SQ_VALU_MFMA_BUSY_CYCLES over SQ_BUSY_CU_CYCLES).
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short_name(k):
+    """HIP kernel name -> the LAUNCH name used by libdnnca's profile table / bench.py."""
+    k = re.sub(r'^void ', '', k)
+    m = re.match(r'dnnca::k_pgbwd<(\d+), (\d+), (\d+), (true|false)', k)
+    if m:
+        return 'pgbwd_%s%sx%s_%s' % ('' if m.group(4) == 'true' else 'w_', m.group(1), m.group(2), m.group(3))
+    m = re.match(r'dnnca::k_pgfwd<(\d+), (\d+), (\d+)', k)
+    if m:
+        return 'pgfwd_%sx%s_%s' % m.groups()
+    m = re.match(r'dnnca::k_(pool2_bwd|pool2_fwd|head_train|head_reduce)<(\d+)', k)
+    if m:
+        return '%s_%s' % m.groups()
+    m = re.match(r'dnnca::k_(tconv2_fwd|tconv2_dgrad|tconv_wgrad)<(\d+), (\d+)', k)
+    if m:
+        return '%s_%s_%s' % m.groups()
+    m = re.match(r'dnnca::(?:ig::|igb::|first::)?k_(\w+)', k)
+    if m:
+        return m.group(1)
+    return k
+
+
+def per_kernel(path):
+    tot, cnt, counter = defaultdict(float), defaultdict(int), None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            counter = r['Counter_Name']
+            n = short_name(r['Kernel_Name'])
+            tot[n] += float(r['Counter_Value'])
+            cnt[n] += 1
+    return tot, cnt, counter
+
+
+def main():
+    mode, a, b = sys.argv[1], sys.argv[2], sys.argv[3]
+    ta, ca, na = per_kernel(a)
+    tb, cb, nb = per_kernel(b)
+    if mode == 'traffic':
+        out = {}
+        for k in sorted(ta, key=lambda k: -ta[k]):
+            fetch_kib = ta[k] / ca[k]
+            write_kib = tb.get(k, 0.0) / max(cb.get(k, 1), 1)
+            out[k] = round((2.0 * fetch_kib + write_kib) * 1024.0, 1)
+        json.dump(out, sys.stdout, indent=1)
+        print()
+    else:
+        print('%-40s %14s %14s %8s' % ('kernel', na, nb, 'ratio'))
+        for k in sorted(ta, key=lambda k: -tb.get(k, 0)):
+            if tb.get(k, 0) > 0:
+                print('%-40s %14.0f %14.0f %8.3f' % (k, ta[k], tb[k], ta[k] / tb[k]))
+
+
+if __name__ == '__main__':
+    main()
