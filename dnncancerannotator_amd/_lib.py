@@ -93,6 +93,7 @@ SIGNATURES = {
     'dnnca_timer_stop': (C.c_int, [_VP, C.POINTER(C.c_float)]),
     'dnnca_profile_enable': (C.c_int, [_VP, C.c_int]),
     'dnnca_profile_focus': (C.c_int, [_VP, C.c_char_p]),
+    'dnnca_profile_sample': (C.c_int, [_VP, C.c_int]),
     'dnnca_profile_reset': (C.c_int, [_VP]),
     'dnnca_profile_count': (C.c_int, [_VP, C.POINTER(C.c_int)]),
     'dnnca_profile_get': (C.c_int, [_VP, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_double),

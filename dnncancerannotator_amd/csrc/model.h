@@ -87,6 +87,7 @@ struct Model {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int prof_mode = 0;                   // 0 off, 1 every launch, 2 only `focus`, 3 every launch keyed by kernel@layer
     const std::string* cur_op = nullptr;
+    int prof_period = 1;                 // mode 2: bracket the focus kernel in one train step out of prof_period
     bool dry = false;
     std::string focus, plan_text;
     std::map<std::string, int> kid;

@@ -60,7 +60,7 @@ bool Model::begin(const char* name, double bytes, double flops) {
         return false;
     }
     if (prof_mode == 0) return true;
-    if (prof_mode == 2 && focus != name) return true;
+    if (prof_mode == 2 && (focus != name || (prof_period > 1 && iterations % prof_period != 0))) return true;
     int id;
     std::string key = name;
     if (prof_mode == 3 && cur_op) key += "@" + *cur_op;          // per-layer table
@@ -903,6 +903,13 @@ int dnnca_profile_enable(void* model, int mode) {
 int dnnca_profile_focus(void* model, const char* kernel_name) {
     MODEL(model);
     M->focus = kernel_name ? kernel_name : "";
+    return DNNCA_OK;
+}
+
+int dnnca_profile_sample(void* model, int period) {
+    MODEL(model);
+    if (period < 1) { set_error("period must be >= 1"); return DNNCA_EINVAL; }
+    M->prof_period = period;
     return DNNCA_OK;
 }
 

@@ -257,7 +257,8 @@ class DeviceModel:
         check(self.lib.dnnca_timer_stop(self.handle, C.byref(ms)))
         return ms.value
 
-    def profile_enable(self, mode=1, focus=None):
+    def profile_enable(self, mode=1, focus=None, period=1):
+        check(self.lib.dnnca_profile_sample(self.handle, int(period)))
         if focus is not None:
             check(self.lib.dnnca_profile_focus(self.handle, focus.encode()))
         check(self.lib.dnnca_profile_enable(self.handle, int(mode)))

@@ -146,6 +146,9 @@ int dnnca_timer_stop(void* model, float* elapsed_ms);  /* synchronises */
 /* per-kernel accounting: when enabled every launch is bracketed by HIP events on the model's stream */
 int dnnca_profile_enable(void* model, int mode /* 0 off, 1 all kernels, 2 only the kernel named by dnnca_profile_focus */);
 int dnnca_profile_focus(void* model, const char* kernel_name);
+/* mode 2 only: bracket the focus kernel in one train step out of `period` (>= 1), so that the brackets of a timed region cost
+   next to nothing; every bracketed launch is a full HIP-event measurement on the launch stream */
+int dnnca_profile_sample(void* model, int period);
 int dnnca_profile_reset(void* model);
 int dnnca_profile_count(void* model, int* count);
 int dnnca_profile_get(void* model, int index, char* name, size_t name_cap, int64_t* launches, double* total_ms,
