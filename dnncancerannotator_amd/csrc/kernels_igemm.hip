@@ -1021,133 +1021,8 @@ __global__ __launch_bounds__(256) void k_igb_wgrad(ig::WgArgs p) {
     }
 }
 
-// forward / data gradient, bf16, 256-pixel x 64-channel block tiles (all unet_big layers).  Versus k_igb_conv: a 16 x 16
-// pixel tile (64 x 64 per wave: 16 MFMAs per 8 fragment reads), the next K chunk's global loads are issued into registers
-// before the current chunk's 144 MFMAs per wave and written to LDS after them, two blocks per CU so that one block's
-// staging overlaps the other's MFMAs, and the blocks that share an input tile (the Cout/64 channel tiles) are neighbours
-// on one XCD (their A patch comes out of that XCD's L2).
-constexpr int T2 = 16;                              // tile edge
+constexpr int T2 = 16;                              // tile edge of the persistent forward / data-gradient kernel
 constexpr int PATCH2 = (T2 + 2) * (T2 + 2);         // 324 staged pixels
-
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_igb_conv2(ConvArgs p, const bf16_t* __restrict__ w16) {
-    __shared__ __attribute__((aligned(16))) bf16_t a_lds[PATCH2 * RS];
-    __shared__ __attribute__((aligned(16))) bf16_t b_lds[9 * 64 * RS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m16 = lane & 15, q = lane >> 4;
-    const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
-    const int nco = nout >> 6, ntiles = p.tiles_x * p.tiles_y * p.B;
-    int tile, cot;
-    {
-        const int id = blockIdx.x;
-        if ((ntiles & 7) == 0) {        // XCD-aware: ids congruent mod 8 share an XCD; keep a tile's channel blocks there
-            const int xcd = id & 7, j = id >> 3;
-            cot = j % nco;
-            tile = (j / nco) * 8 + xcd;
-        } else {
-            cot = id % nco;
-            tile = id / nco;
-        }
-    }
-    const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
-    const int x0 = bx * T2, y0 = by * T2;
-    const int co0 = cot * 64;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    constexpr int AU = (PATCH2 * 8 + 255) / 256, BU = 9 * 64 * 4 / 256;        // 11 float4 and 9 uint4 per thread
-    float4 ar[AU];
-    u32x4 br[BU];
-    auto issue = [&](int cc) {
-        const bool second = cc >= p.c_src0;
-        const float* src = second ? p.src[1] : p.src[0];
-        const int cs = second ? p.c_src1 : p.c_src0, c0 = second ? cc - p.c_src0 : cc;
-#pragma unroll
-        for (int u = 0; u < AU; ++u) {
-            const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
-            const int ly = px / (T2 + 2), lx = px - ly * (T2 + 2);
-            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
-            ar[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (px < PATCH2 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                ar[u] = *reinterpret_cast<const float4*>(src + (((size_t)b * p.H + iy) * p.W + ix) * cs + c0 + 4 * c4);
-        }
-#pragma unroll
-        for (int u = 0; u < BU; ++u) {
-            const int i = tid + 256 * u, part = i & 3, r = i >> 2;         // r = tap * 64 + n
-            const int tap = r >> 6, n = r & 63;
-            br[u] = *reinterpret_cast<const u32x4*>(w16 + ((size_t)tap * nout + co0 + n) * kin + cc + 8 * part);
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int u = 0; u < AU; ++u) {
-            const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
-            if (px >= PATCH2) continue;
-            bf16x4 h;
-            h[0] = (bf16_t)ar[u].x; h[1] = (bf16_t)ar[u].y; h[2] = (bf16_t)ar[u].z; h[3] = (bf16_t)ar[u].w;
-            *reinterpret_cast<bf16x4*>(a_lds + px * RS + 4 * c4) = h;
-        }
-#pragma unroll
-        for (int u = 0; u < BU; ++u) {
-            const int i = tid + 256 * u, part = i & 3, r = i >> 2;
-            *reinterpret_cast<u32x4*>(b_lds + r * RS + 8 * part) = br[u];
-        }
-    };
-
-    issue(0);
-#pragma unroll 1
-    for (int cc = 0; cc < kin; cc += CK) {
-        lds_barrier();              // the previous chunk's fragment reads are complete
-        commit();
-        if (cc + CK < kin) issue(cc + CK);
-        lds_barrier();
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            bf16x8 bv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(b_lds + (tap * 64 + 16 * j + m16) * RS + 8 * q);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bf16x8 av = *reinterpret_cast<const bf16x8*>(a_lds + ((4 * wave + r + dy) * (T2 + 2) + m16 + dx) * RS + 8 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[r][j], 0, 0, 0);
-            }
-        }
-    }
-    // epilogue: D[pixel 4q+i of row 4 wave + r][channel 16j + m16]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int y = y0 + 4 * wave + r;
-        if (y >= p.H) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int co = co0 + 16 * j + m16;
-            const int which = co >= p.n_dst0;
-            const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co - p.n_dst0 : co;
-            const float bias = (MODE == 0 && p.bias) ? p.bias[co] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int x = x0 + 4 * q + i;
-                if (x >= p.W) continue;
-                const size_t o = (((size_t)b * p.H + y) * p.W + x) * cw + cl;
-                float v = acc[r][j][i];
-                if (MODE == 0) {
-                    v += bias;
-                    v = p.alpha < 0.f ? v : (v > 0.f ? v : p.alpha * v);
-                } else {
-                    if (p.acc[which]) v += p.dst[which][o];
-                    if (p.mask[which]) v *= p.mask[which][o] > 0.f ? 1.0f : p.alpha;
-                }
-                p.dst[which][o] = v;
-            }
-        }
-    }
-}
 
 // forward / data gradient, bf16, persistent and software-pipelined (one block per CU, the whole register file):
 //   work item = (pixel tile, channel tile, K chunk); a block walks its items in order, accumulators restart at chunk 0;
@@ -1833,9 +1708,11 @@ int ig_begin_backward(Model* m) {
 
 // will launch_ig / launch_igb take the persistent kernel (k_ig_conv3 / k_igb_conv3) for these arguments?
 static bool conv3_path(const ig::ConvArgs& a, int cout, bool bf16) {
-    if (bf16) return cout % 64 == 0 && a.c_src0 % 32 == 0 && a.c_src1 % 32 == 0 && a.n_dst0 % 64 == 0 && !getenv("DNNCA_CONV2");
+    // the persistent kernels address their sources with 32-bit byte offsets (bit 31 marks "outside the image")
     const int cmax = a.c_src0 > a.c_src1 ? a.c_src0 : a.c_src1;
-    return !getenv("DNNCA_IGCONV1") && (double)a.B * a.H * a.W * cmax * 4.0 < 2.0e9 && 9.0 * cout * (a.c_src0 + a.c_src1) * 4.0 < 2.0e9;
+    const bool fits = (double)a.B * a.H * a.W * cmax * 4.0 < 2.0e9 && 9.0 * cout * (a.c_src0 + a.c_src1) * 4.0 < 2.0e9;
+    if (bf16) return fits && cout % 64 == 0 && a.c_src0 % 32 == 0 && a.c_src1 % 32 == 0 && a.n_dst0 % 64 == 0;
+    return fits && !getenv("DNNCA_IGCONV1");
 }
 static int conv3_rows(const ig::ConvArgs& a) { return ((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B; }     // 16 x 16 pixel tiles
 
@@ -1869,17 +1746,13 @@ template <int MODE>
 static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, int cout, const char* name, double bytes,
                        double flops) {
     const int nn = pick_nn(cout);
-    if (cout % 64 == 0 && a.c_src0 % 32 == 0 && a.c_src1 % 32 == 0) {
+    if (conv3_path(a, cout, true)) {
         ig::ConvArgs a2 = a;
         a2.tiles_x = (a.W + igb::T2 - 1) / igb::T2;
         a2.tiles_y = (a.H + igb::T2 - 1) / igb::T2;
         const unsigned nblocks = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / 64));
-        if (conv3_path(a, cout, true)) {          // DNNCA_CONV2 (tuning aid) selects the non-persistent variant
-            const unsigned g = nblocks < 256u ? nblocks : 256u;
-            LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE>), dim3(g), dim3(256), 0, m->stream, a2, w16));
-            return;
-        }
-        LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv2<MODE>), dim3(nblocks), dim3(256), 0, m->stream, a2, w16));
+        const unsigned g = nblocks < 256u ? nblocks : 256u;
+        LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE>), dim3(g), dim3(256), 0, m->stream, a2, w16));
         return;
     }
     dim3 grid(a.tiles_x * a.tiles_y * a.B, cout / (16 * nn));
