@@ -184,6 +184,9 @@ struct WgArgs {
     int cs, ci_off, cin_total, cout;
     int B, H, W;
     int tiles_x, tiles_y, psplit;
+    // same-address atomics execute one after the other (~56 ns each): when many blocks share a small gradient, block b adds
+    // into copy b % nbuckets of it (dw / dbias then point at copy 0, copies bucket_stride floats apart; k_wg_fold sums them)
+    int nbuckets, bucket_stride;
 };
 
 // grid: x = pixel split, y = input-channel chunk (16), z = output-channel tile (16*NN)
@@ -283,8 +286,11 @@ __global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
     constexpr int XQ = CIT / 4, GQ = COT / 4;                                           // float4 per pixel
     constexpr int XU = (PPATCH * XQ + 255) / 256, GU = NPX * GQ / 256;
     constexpr int NKS = NPX / 4 / WK;                                                   // K-steps per wave per tile
-    __shared__ __attribute__((aligned(16))) float x_lds[PPATCH * XS + 16];
-    __shared__ __attribute__((aligned(16))) float g_lds[NPX * GS];
+    constexpr int XF = PPATCH * XS + 16, GF = NPX * GS;
+    constexpr int RF = MW * (9 * NN + 1) * 256;          // buffer of the in-block reduction (overlays the staged tiles)
+    __shared__ __attribute__((aligned(16))) float smem[XF + GF > RF ? XF + GF : RF];
+    float* x_lds = smem;
+    float* g_lds = smem + XF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4;
     const int wm = wave % MW, wk = wave / MW;
@@ -380,18 +386,63 @@ __global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
             mfma_step(a1, b1);
         }
     }
-    // D[ci = 16 wm + 4q + i][co = 16j + m16]; the WK pixel-split waves add their partial sums like other blocks do
+    // the WK pixel-split waves of a channel tile first add up inside the block (through the staged-tile LDS, one wave set
+    // at a time), then wave set 0 adds into the gradient (copy blockIdx.x % nbuckets of it)
+    if (WK > 1) {
+        float* red = smem + wm * ((9 * NN + 1) * 256);
+        for (int r = 1; r < WK; ++r) {
+            __syncthreads();
+            if (wk == r) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) red[((t * NN + j) * 4 + i) * 64 + lane] = acc[t][j][i];
+#pragma unroll
+                for (int j = 0; j < NN; ++j) red[9 * NN * 256 + j * 64 + lane] = accb[j][0];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[t][j][i] += red[((t * NN + j) * 4 + i) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < NN; ++j) accb[j][0] += red[9 * NN * 256 + j * 64 + lane];
+            }
+        }
+    }
+    if (wk != 0) return;
+    const size_t boff = (size_t)(p.nbuckets > 1 ? blockIdx.x % p.nbuckets : 0) * p.bucket_stride;
+    // D[ci = 16 wm + 4q + i][co = 16j + m16]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < NN; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                atomicAdd(p.dw + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
+                atomicAdd(p.dw + boff + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
     if (do_bias && q == 0) {
 #pragma unroll
-        for (int j = 0; j < NN; ++j) atomicAdd(p.dbias + co0 + 16 * j + m16, accb[j][0]);     // row 0 of the all-ones A
+        for (int j = 0; j < NN; ++j) atomicAdd(p.dbias + boff + co0 + 16 * j + m16, accb[j][0]);     // row 0 of the all-ones A
     }
+}
+
+// sum of the bucket copies of a small weight gradient: dst[i] += sum_b slabs[b][i]; the copies are left zeroed for the next use
+__global__ __launch_bounds__(256) void k_wg_fold(float* __restrict__ slabs, int nb, int stride, int n_w, float* __restrict__ dw,
+                                                 float* __restrict__ dbias, int n_b) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_w + n_b) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        s += slabs[(size_t)b * stride + i];
+        slabs[(size_t)b * stride + i] = 0.f;
+    }
+    if (i < n_w) dw[i] += s;
+    else dbias[i - n_w] += s;
 }
 
 // forward / data gradient, fp32, persistent and software-pipelined: the f32 twin of igb::k_igb_conv3 (see there for the
@@ -1619,7 +1670,9 @@ struct IgPlan {
     igb::bf16_t* wf = nullptr;
     igb::bf16_t* wd = nullptr;
     int max_wb = 0;
+    float* wg_slabs = nullptr;       // WG_BUCKETS copies of a small layer's weight + bias gradient (ig_wgrad2; left zeroed by k_wg_fold)
 };
+constexpr int WG_BUCKETS = 16, WG_SLAB_FLOATS = 131072 + 1024;
 static std::map<Model*, IgPlan> g_ig;
 
 void ig_release(Model* m) { g_ig.erase(m); }
@@ -1798,13 +1851,31 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         LAUNCH(m, "g_act_bwd", 3 * out_bytes, out_bytes / 4,
                g_act_bwd(m->stream, (size_t)B * o.out.d.H * o.out.d.W * CO, o.out.g.p, o.out.d.p, o.alpha));
     const int tiles_x = (o.out.d.W + ig::TX - 1) / ig::TX, tiles_y = (o.out.d.H + ig::TY - 1) / ig::TY;
+    // small gradients shared by many blocks go through bucket copies (see WgArgs::nbuckets); fp32 second-generation kernel only
+    const int n_w = 9 * (CA + CB) * CO;
+    bool bucketed = false;
+    auto wgrad2_path = [&](int cs) {        // the launch condition of k_ig_wgrad2 below
+        return !use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (cs > CO ? cs : CO) * 4.0 < 2.0e9 && !getenv("DNNCA_WGRAD1");
+    };
+    auto wgrad2_psplit = [&](int cs) {
+        const int mw = cs % 64 == 0 ? 4 : (cs % 32 == 0 ? 2 : 1), nn = pick_nn(CO);
+        const int combos = (cs / (16 * mw)) * (CO / (16 * nn));
+        return (256 + combos - 1) / combos;
+    };
+    if (!m->dry && wgrad2_path(CA) && (!CB || wgrad2_path(CB)) && n_w + CO <= WG_SLAB_FLOATS && wgrad2_psplit(CA) > 32 &&
+        !getenv("DNNCA_NO_WG_BUCKETS")) {
+        if (!pl.wg_slabs && m->alloc((void**)&pl.wg_slabs, (size_t)WG_BUCKETS * WG_SLAB_FLOATS * 4) != DNNCA_OK) pl.wg_slabs = nullptr;
+        bucketed = pl.wg_slabs != nullptr;
+    }
     // weight (+bias) gradient, one launch per source
     for (int s = 0; s < (CB ? 2 : 1); ++s) {
         ig::WgArgs w{};
         w.x = s == 0 ? o.inA.d.p : o.inB.d.p;
         w.dz = o.out.g.p;
-        w.dw = m->g + o.w_off;
-        w.dbias = s == 0 ? m->g + o.b_off : nullptr;
+        w.dw = bucketed ? pl.wg_slabs : m->g + o.w_off;
+        w.dbias = s == 0 ? (bucketed ? pl.wg_slabs + n_w : m->g + o.b_off) : nullptr;
+        w.nbuckets = bucketed ? WG_BUCKETS : 1;
+        w.bucket_stride = WG_SLAB_FLOATS;
         w.cs = s == 0 ? CA : CB;
         w.ci_off = s == 0 ? 0 : CA;
         w.cin_total = CA + CB;
@@ -1848,6 +1919,10 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         else if (nn == 2) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<2>), grid, dim3(256), 0, m->stream, w));
         else LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<1>), grid, dim3(256), 0, m->stream, w));
     }
+    if (bucketed)
+        LAUNCH(m, "wg_fold", 4.0 * WG_BUCKETS * (n_w + CO), 0,
+               hipLaunchKernelGGL(ig::k_wg_fold, dim3((n_w + CO + 255) / 256), dim3(256), 0, m->stream, pl.wg_slabs, WG_BUCKETS,
+                                  WG_SLAB_FLOATS, n_w, m->g + o.w_off, m->g + o.b_off, CO));
     if (o.need_din) {
         ig::ConvArgs a{};
         a.src[0] = o.out.g.p; a.c_src0 = CO; a.c_src1 = 0;
