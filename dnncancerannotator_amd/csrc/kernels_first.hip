@@ -21,12 +21,13 @@ struct Args {
     const float* bias;   // [CO]
     float* y;            // forward output / backward: activated output (mask source), dense NHWC
     const float* dy;     // backward: gradient of the output
-    float* dw;           // [9][CO]
+    float* dw;           // [9][CO]   (backward: copy 0 of the bucket copies, see k_first_wgrad)
     float* db;           // [CO]
     int B, H, W, CO;
     int tiles_x, tiles_y, ntiles;
     float alpha;         // forward: activation slope (<0 none).  backward: slope of act' when `mask`
     int mask;
+    int nbuckets, bucket_stride;     // backward: block b adds into copy b % nbuckets (copies bucket_stride floats apart)
 };
 
 __device__ __forceinline__ void stage_patch(const Args& p, float* xs, int b, int y0, int x0) {
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void k_first_fwd(Args p) {
     }
 }
 
-// persistent blocks; per-thread partial sums over the block's tiles, one LDS reduction and 10*CO atomics per block
+// persistent blocks; per-thread partial sums over the block's tiles, one LDS reduction and 10*CO atomics per block into one of
+// FIRST_BUCKETS copies of the gradient (a thousand same-address atomics would take longer than the pass itself: they execute
+// one after the other, ~56 ns each); k_first_fold sums the copies and leaves them zeroed
 __global__ __launch_bounds__(256) void k_first_wgrad(Args p) {
     __shared__ float xs[PH * PW];
     __shared__ float red[256 * 4];
@@ -126,9 +129,22 @@ __global__ __launch_bounds__(256) void k_first_wgrad(Args p) {
             const int c = threadIdx.x;          // channel c = 4*cq' + k lives at red[4*(l*G + cq') + k] = red[4*l*G + c]
             float s = 0.f;
             for (int l = 0; l < PL; ++l) s += red[4 * l * G + c];
-            atomicAdd((t < 9 ? p.dw + t * p.CO : p.db) + c, s);
+            atomicAdd((t < 9 ? p.dw + t * p.CO : p.db) + (size_t)(blockIdx.x % p.nbuckets) * p.bucket_stride + c, s);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_first_fold(float* __restrict__ slabs, int nb, int stride, int n, float* __restrict__ dw,
+                                                    float* __restrict__ db, int n_w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        s += slabs[(size_t)b * stride + i];
+        slabs[(size_t)b * stride + i] = 0.f;
+    }
+    if (i < n_w) dw[i] += s;
+    else db[i - n_w] += s;
 }
 
 }  // namespace first
@@ -170,8 +186,17 @@ bool fast_first_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_byt
     a.mask = (o.alpha >= 0.f && !o.premasked) ? 1 : 0;
     a.alpha = o.alpha;
     const int blocks = a.ntiles < 1024 ? a.ntiles : 1024;
+    constexpr int FIRST_BUCKETS = 32, STRIDE = 10 * 256;      // CO <= 256
+    if (!m->first_slabs && !m->dry && m->alloc((void**)&m->first_slabs, (size_t)FIRST_BUCKETS * STRIDE * 4) != DNNCA_OK) return false;
+    a.dw = m->first_slabs;
+    a.db = m->first_slabs + 9 * a.CO;
+    a.nbuckets = FIRST_BUCKETS;
+    a.bucket_stride = STRIDE;
     LAUNCH(m, "first_wgrad", out_bytes * (a.mask ? 2 : 1) + in_bytes, flops,
            hipLaunchKernelGGL(first::k_first_wgrad, dim3(blocks), dim3(256), 0, m->stream, a));
+    LAUNCH(m, "first_fold", 4.0 * FIRST_BUCKETS * 10 * a.CO, 0,
+           hipLaunchKernelGGL(first::k_first_fold, dim3((10 * a.CO + 255) / 256), dim3(256), 0, m->stream, m->first_slabs, FIRST_BUCKETS,
+                              STRIDE, 10 * a.CO, m->g + o.w_off, m->g + o.b_off, 9 * a.CO));
     return true;
 }
 

@@ -565,14 +565,22 @@ __global__ void k_loss(size_t n, const float* __restrict__ logits, const float* 
         if (dlogits) dlogits[i] = mask * (sig - z) * grad_scale;
         if (prob) prob[i] = sig;
     }
-    double d = wave_sum_d((double)acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(scalars + 3, d);
+    // one atomic per block, a few hundred blocks at most: same-address atomics execute one after the other (~56 ns each)
+    __shared__ double red[TB / 64];
+    const double d = wave_sum_d((double)acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TB / 64; ++w) t += red[w];
+        atomicAdd(scalars + 3, t);
+    }
 }
 
 void g_loss(hipStream_t s, size_t n, const float* logits, const float* y, const dnnca_loss_cfg cfg, double n_label,
             double* scalars, float* dlogits, float* prob, float grad_scale) {
     unsigned blocks = nblk(n, TB * 8);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(k_loss, dim3(blocks), dim3(TB), 0, s, n, logits, y, cfg, n_label, scalars, dlogits, prob, grad_scale);
 }
 
@@ -596,13 +604,21 @@ __global__ void k_l2(size_t n, const float* __restrict__ w, float* __restrict__ 
         acc = fmaf(v, v, acc);
         g[i] = fmaf(2.0f * l2, v, g[i]);
     }
-    double d = wave_sum_d((double)acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(scalars + 4, d * (double)l2);
+    // one atomic per block, few blocks: same-address atomics execute one after the other (~56 ns each)
+    __shared__ double red[TB / 64];
+    const double d = wave_sum_d((double)acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TB / 64; ++w) t += red[w];
+        atomicAdd(scalars + 4, t * (double)l2);
+    }
 }
 
 void g_l2(hipStream_t s, size_t n, const float* w, float* g, float l2, double* scalars) {
     unsigned blocks = nblk(n, TB * 4);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 128) blocks = 128;
     hipLaunchKernelGGL(k_l2, dim3(blocks), dim3(TB), 0, s, n, w, g, l2, scalars);
 }
 
@@ -656,18 +672,24 @@ __global__ void k_confusion(size_t n, const float* __restrict__ prob, const floa
         }
         double d0 = wave_sum_d((double)tp), d1 = wave_sum_d((double)fp), d2 = wave_sum_d((double)fn),
                d3 = wave_sum_d((double)tn);
+        // block-level sums first: one atomic per block and counter (same-address atomics serialise)
+        __shared__ double red[TB / 64][4];
+        __syncthreads();
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(out4 + 4 * t + 0, d0);
-            atomicAdd(out4 + 4 * t + 1, d1);
-            atomicAdd(out4 + 4 * t + 2, d2);
-            atomicAdd(out4 + 4 * t + 3, d3);
+            red[threadIdx.x >> 6][0] = d0; red[threadIdx.x >> 6][1] = d1; red[threadIdx.x >> 6][2] = d2; red[threadIdx.x >> 6][3] = d3;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            double a = 0.0;
+            for (int w = 0; w < TB / 64; ++w) a += red[w][threadIdx.x];
+            atomicAdd(out4 + 4 * t + threadIdx.x, a);
         }
     }
 }
 
 void g_confusion(hipStream_t s, size_t n, const float* prob, const float* y, const float* thr, int nthr, double* out4) {
     unsigned blocks = nblk(n, TB * 16);
-    if (blocks > 512) blocks = 512;
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(k_confusion, dim3(blocks), dim3(TB), 0, s, n, prob, y, thr, nthr, out4);
 }
 
