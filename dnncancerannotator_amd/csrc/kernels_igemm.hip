@@ -848,6 +848,152 @@ __global__ __launch_bounds__(256) void k_ig_tconv_wgrad(TcArgs p) {
     }
 }
 
+// weight gradient of the transposed conv, second generation (fp32): dW[ae][co][ci] = sum_p dout[out(p, ae)][co] * in[p][ci].
+// Block tile = 16*MW output channels x 16*NN input channels x 4 parities, one persistent block per CU; the four waves split
+// the output channels MW ways and the pixels 4/MW ways; `in` and the four parity slices of `dout` are read once per
+// channel-tile pair (the first generation re-read `in` per parity and per 16-channel chunk); next tile prefetched into
+// registers by raw buffer loads; in-block reduction over the pixel-split waves before the atomics.
+template <int MW, int NN>
+__global__ __launch_bounds__(256, 1) void k_ig_tconv_wgrad2(TcArgs p) {
+    constexpr int COT = 16 * MW, CIT = 16 * NN, WK = 4 / MW;
+    constexpr int TM = (4 / MW) < (4 / NN) ? (4 / MW) : (4 / NN);
+    constexpr int NPX = 64 * TM;                                  // input pixels per tile (K)
+    constexpr int GS = COT + (COT == 16 ? 0 : 16), XS = CIT + (CIT == 16 ? 0 : 16);
+    constexpr int GQ = COT / 4, XQ = CIT / 4;
+    constexpr int GU = 4 * NPX * GQ / 256, XU = NPX * XQ / 256;
+    constexpr int NKS = NPX / 4 / WK;
+    constexpr int GF = 4 * NPX * GS, XF = NPX * XS;
+    constexpr int RF = MW * (4 * NN + 1) * 256;
+    static_assert(NPX * XQ % 256 == 0 && NKS % 2 == 0, "tile geometry");
+    __shared__ __attribute__((aligned(16))) float smem[GF + XF > RF ? GF + XF : RF];
+    float* g_lds = smem;              // [parity][pixel][GS]
+    float* x_lds = smem + GF;         // [pixel][XS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int wm = wave % MW, wk = wave / MW;
+    const int co0 = blockIdx.y * COT, n0 = blockIdx.z * CIT;
+    const bool do_bias = p.dbias && blockIdx.z == 0;
+    const int ntiles = (p.npix + NPX - 1) / NPX;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((size_t)p.npix * p.cin * 4), WG_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.dout, 0, (unsigned)((size_t)p.npix * 4 * p.cout * 4), WG_FLAGS);
+
+    f32x4 acc[4][NN], accb[4];
+#pragma unroll
+    for (int ae = 0; ae < 4; ++ae) {
+        accb[ae] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[ae][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    wg_u32x4 xr[XU], gr[GU];
+    auto issue = [&](int tile) {
+        const unsigned oob = tile < ntiles ? 0u : WG_OOB;
+        const int p0 = (tile < ntiles ? tile : 0) * NPX;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 256 * u, px = i / XQ, c4 = i % XQ;
+            const unsigned off = (p0 + px < p.npix ? (unsigned)((((p0 + px) * p.cin) + n0 + 4 * c4) * 4) : WG_OOB) | oob;
+            xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 256 * u, c4 = i % GQ, r = i / GQ, px = r % NPX, ae = r / NPX;
+            const int pp = p0 + px, jx = pp % p.W, bi = pp / p.W;
+            const unsigned opix = (unsigned)((bi * 2 + (ae >> 1)) * (2 * p.W) + 2 * jx + (ae & 1));
+            const unsigned off = (pp < p.npix ? (opix * (unsigned)p.cout + co0 + 4 * c4) * 4u : WG_OOB) | oob;
+            gr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsg, off, 0, 0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 256 * u, px = i / XQ, c4 = i % XQ;
+            *reinterpret_cast<wg_u32x4*>(x_lds + px * XS + 4 * c4) = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 256 * u, c4 = i % GQ, r = i / GQ;       // r = parity * NPX + pixel
+            *reinterpret_cast<wg_u32x4*>(g_lds + r * GS + 4 * c4) = gr[u];
+        }
+    };
+    auto load_step = [&](int s, float (&av)[4], float (&bv)[NN]) {
+        const int px = 4 * (wk + WK * s) + q;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) bv[j] = x_lds[px * XS + 16 * j + m16];
+#pragma unroll
+        for (int ae = 0; ae < 4; ++ae) av[ae] = g_lds[(ae * NPX + px) * GS + 16 * wm + m16];
+    };
+    auto mfma_step = [&](const float (&av)[4], const float (&bv)[NN]) {
+#pragma unroll
+        for (int ae = 0; ae < 4; ++ae) {
+#pragma unroll
+            for (int j = 0; j < NN; ++j) acc[ae][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ae], bv[j], acc[ae][j], 0, 0, 0);
+            if (do_bias) accb[ae] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ae], 1.0f, accb[ae], 0, 0, 0);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+#pragma unroll 1
+    for (; tile < ntiles; tile += p.psplit) {
+        lds_barrier();
+        commit();
+        issue(tile + p.psplit);
+        lds_barrier();
+        float a0[4], b0[NN], a1[4], b1[NN];
+        load_step(0, a0, b0);
+#pragma unroll 1
+        for (int s = 0; s < NKS; s += 2) {
+            load_step(s + 1, a1, b1);
+            mfma_step(a0, b0);
+            load_step(s + 2 < NKS ? s + 2 : 0, a0, b0);
+            mfma_step(a1, b1);
+        }
+    }
+    // bias gradient of a row co = sum over the four parities (all 16 columns of the all-ones-B product are equal)
+    float bsum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bsum[i] = (accb[0][i] + accb[1][i]) + (accb[2][i] + accb[3][i]);
+    if (WK > 1) {       // the pixel-split wave sets add up inside the block first (one set at a time through LDS)
+        float* red = smem + wm * ((4 * NN + 1) * 256);
+        for (int r = 1; r < WK; ++r) {
+            __syncthreads();
+            if (wk == r) {
+#pragma unroll
+                for (int ae = 0; ae < 4; ++ae)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) red[((ae * NN + j) * 4 + i) * 64 + lane] = acc[ae][j][i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[4 * NN * 256 + i * 64 + lane] = bsum[i];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int ae = 0; ae < 4; ++ae)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[ae][j][i] += red[((ae * NN + j) * 4 + i) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bsum[i] += red[4 * NN * 256 + i * 64 + lane];
+            }
+        }
+    }
+    if (wk != 0) return;
+    // D[co = 16 wm + 4q + i][ci = 16j + m16]
+#pragma unroll
+    for (int ae = 0; ae < 4; ++ae)
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(p.dw + ((size_t)ae * p.cout + co0 + 16 * wm + 4 * q + i) * p.cin + n0 + 16 * j + m16, acc[ae][j][i]);
+    if (do_bias && m16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(p.dbias + co0 + 16 * wm + 4 * q + i, bsum[i]);
+    }
+}
+
 }  // namespace ig
 
 // ================================================================================================ bf16 variants
@@ -2000,7 +2146,22 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
                hipLaunchKernelGGL(igb::k_igb_tconv_dgrad, dim3((a.npix + 127) / 128, a.cin / 64), dim3(256), 0, m->stream, a, pl.wd + o.w_off));
         return true;
     }
-    {
+    if ((double)a.npix * 4.0 * a.cout * 4.0 < 2.0e9 && (double)a.npix * a.cin * 4.0 < 2.0e9 && !getenv("DNNCA_TCWGRAD1")) {
+        // second generation: (16 mw x 16 nn) channel tiles x 4 parities, 32-bit byte offsets
+        const int mw = a.cout % 64 == 0 ? 4 : (a.cout % 32 == 0 ? 2 : 1), nn = pick_nn(a.cin);
+        const int tm = (4 / mw) < (4 / nn) ? (4 / mw) : (4 / nn);
+        const int ntiles = (a.npix + 64 * tm - 1) / (64 * tm);
+        const int combos = (a.cout / (16 * mw)) * (a.cin / (16 * nn));
+        int ps = (256 + combos - 1) / combos;
+        if (ps > ntiles) ps = ntiles;
+        a.psplit = ps < 1 ? 1 : ps;
+        dim3 g2(a.psplit, a.cout / (16 * mw), a.cin / (16 * nn));
+#define TW2(MWv, NNv) LAUNCH(m, "ig_tconv_wgrad2", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad2<MWv, NNv>), g2, dim3(256), 0, m->stream, a))
+        if (mw == 4) { if (nn == 4) TW2(4, 4); else if (nn == 2) TW2(4, 2); else TW2(4, 1); }
+        else if (mw == 2) { if (nn == 4) TW2(2, 4); else if (nn == 2) TW2(2, 2); else TW2(2, 1); }
+        else { if (nn == 4) TW2(1, 4); else if (nn == 2) TW2(1, 2); else TW2(1, 1); }
+#undef TW2
+    } else {
         const int nn = pick_nn(a.cin);
         const int ntiles = (a.npix + 127) / 128;
         const int combos = (a.cout / 16) * 4 * (a.cin / (16 * nn));
