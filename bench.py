@@ -68,7 +68,7 @@ def rendezvous(rank, world):
         time.sleep(0.05)
 
 
-def cpu_baseline(sample_steps=3):
+def cpu_baseline(sample_steps=6):
     """The numpy oracle (a port: TensorFlow, the reference's CPU back-end, is not installed anywhere) timed on this
     host on a bounded sample of the same workload: `sample_steps` train steps of one 8-slice batch."""
     from oracle import unet_oracle as O
