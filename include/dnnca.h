@@ -31,7 +31,10 @@ extern "C" {
 
 enum { DNNCA_ARCH_UNET = 0, DNNCA_ARCH_MULMO = 1 };     /* models/tf_models/unet.py:194 UNetAnnotator, :285 MulmoUNetAnnotator */
 enum { DNNCA_PAD_VALID = 0, DNNCA_PAD_SAME = 1 };       /* model_options.padding (configs/unet.yaml:9) */
-enum { DNNCA_F32 = 0, DNNCA_BF16 = 1 };                 /* arithmetic type of the conv contractions */
+/* arithmetic type of the conv contractions.  DNNCA_BF16: the operands of the 3x3 convolutions with >= 32 channels and of the
+   transposed convolutions with channel counts that are multiples of 64 are rounded to bfloat16 (round to nearest even) on
+   their way into the matrix cores; weights, activations, gradients and every accumulation stay float32 */
+enum { DNNCA_F32 = 0, DNNCA_BF16 = 1 };
 enum { DNNCA_UNIQUE_ID_BYTES = 128 };
 
 /* model_options of configs/{unet,unet_big,mulmo_unet}.yaml (unet.py:195-207) + the input element spec
