@@ -43,6 +43,10 @@ class StepOut(C.Structure):
                 ('label_min', C.c_float), ('label_max', C.c_float)]
 
 
+class AugParam(C.Structure):                       # dnnca_aug_param
+    _fields_ = [('dy', C.c_int32), ('dx', C.c_int32), ('flip', C.c_int32), ('contrast', C.c_float)]
+
+
 class Confusion(C.Structure):
     _fields_ = [('tp', C.c_double), ('fp', C.c_double), ('fn', C.c_double), ('tn', C.c_double)]
 
@@ -77,6 +81,8 @@ SIGNATURES = {
     'dnnca_dev_alloc': (C.c_int, [C.POINTER(_VP), C.c_size_t]),
     'dnnca_dev_free': (C.c_int, [_VP]),
     'dnnca_memcpy_h2d': (C.c_int, [_VP, _VP, C.c_size_t]),
+    'dnnca_augment_u8': (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(AugParam), C.c_int, C.c_int,
+                                   _VP, _VP]),
     'dnnca_memcpy_d2h': (C.c_int, [_VP, _VP, C.c_size_t]),
     'dnnca_train_step_dev': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_float, C.POINTER(LossCfg), C.POINTER(StepOut)]),
     'dnnca_forward_dev': (C.c_int, [_VP, _VP, C.c_int, C.c_int]),

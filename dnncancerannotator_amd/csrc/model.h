@@ -68,6 +68,8 @@ struct Model {
     float* out5 = nullptr;               // = g + nT : [loss, positive_rate, weight, ymin, ymax]
     float *x_stage = nullptr, *y_stage = nullptr, *logits = nullptr, *dlogits = nullptr, *prob = nullptr;
     float* thr_dev = nullptr;
+    void* aug_scratch = nullptr;         // per-image augmentation draws + channel sums (kernels_aug.hip)
+    size_t aug_scratch_bytes = 0;
     float* first_slabs = nullptr;        // bucket copies of the first-layer weight gradient (kernels_first.hip; kept zeroed)
     void* bn_part = nullptr;             // partials table of the tuned BN reductions (kernels_misc.hip)
     size_t bn_part_bytes = 0;

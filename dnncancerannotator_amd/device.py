@@ -52,6 +52,48 @@ class DeviceBuffer:
             pass
 
 
+class RawDeviceBuffer:
+    """An HBM allocation of `nbytes` bytes (uint8 source batches of the device-side augmentation; grown on demand)."""
+
+    def __init__(self):
+        self.ptr, self.nbytes = C.c_void_p(), 0
+
+    def reserve(self, nbytes):
+        if nbytes > self.nbytes:
+            self.free()
+            check(_lib.load().dnnca_dev_alloc(C.byref(self.ptr), nbytes))
+            self.nbytes = nbytes
+
+    def upload(self, array):
+        array = np.ascontiguousarray(array)
+        self.reserve(array.nbytes)
+        check(_lib.load().dnnca_memcpy_h2d(self.ptr, array.ctypes.data_as(C.c_void_p), array.nbytes))
+
+    def free(self):
+        if self.ptr:
+            _lib.load().dnnca_dev_free(self.ptr)
+            self.ptr, self.nbytes = C.c_void_p(), 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceView:
+    """A float32 tensor inside a RawDeviceBuffer (what train_step_dev takes: .ptr and .shape)."""
+
+    def __init__(self, buf, shape):
+        self.buf, self.ptr, self.shape = buf, buf.ptr, tuple(shape)
+        self.nbytes = int(np.prod(shape)) * 4
+
+    def to_host(self):
+        out = np.empty(self.shape, np.float32)
+        check(_lib.load().dnnca_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+
 class DeviceModel:
     def __init__(self, arch, in_channels, height, width, max_batch, n_filters_first, n_downsample, rate=2, kernel_size=3,
                  conv_stride=1, bn=False, padding='valid', leaky_alpha=0.0, l2=0.0, reference_index=0, n_conv=2,
@@ -226,6 +268,32 @@ class DeviceModel:
         out = (_lib.Confusion * thr.size)()
         check(self.lib.dnnca_pixel_confusion(self.handle, fptr(y), y.shape[0], fptr(thr), thr.size, out))
         return [(c.tp, c.fp, c.fn, c.tn) for c in out]
+
+    # ---- device-side augmentation (annotator/data.py:62-111 train_ds) ------------------------------------------
+    def augment_u8(self, raw, params, out_size, label_index, contrast_channels=None):
+        """raw uint8 [B, Hs, Ws, Cs] (host) + per-image draws [(dy, dx, flip, contrast)] -> device-resident (x [B, Ho, Wo, Cs-1],
+        y [B, Ho, Wo]) views, valid until the next call.  contrast_channels: source channels to adjust (default: all features)."""
+        raw = np.ascontiguousarray(raw, np.uint8)
+        if raw.ndim != 4:
+            raise ValueError('raw batch must be [B, H, W, C] uint8, got %s' % (raw.shape,))
+        B, hs, ws, cs = raw.shape
+        ho, wo = int(out_size[0]), int(out_size[1])
+        if len(params) != B:
+            raise ValueError('%d parameter rows for %d images' % (len(params), B))
+        if contrast_channels is None:
+            contrast_channels = [c for c in range(cs) if c != label_index]
+        mask = 0
+        for c in contrast_channels:
+            mask |= 1 << int(c)
+        if not hasattr(self, '_aug'):
+            self._aug = (RawDeviceBuffer(), RawDeviceBuffer(), RawDeviceBuffer())
+        src, xb, yb = self._aug
+        src.upload(raw)
+        xb.reserve(B * ho * wo * (cs - 1) * 4)
+        yb.reserve(B * ho * wo * 4)
+        prm = (_lib.AugParam * B)(*[_lib.AugParam(int(p[0]), int(p[1]), int(p[2]), float(p[3])) for p in params])
+        check(self.lib.dnnca_augment_u8(self.handle, src.ptr, B, hs, ws, cs, int(label_index), mask, prm, ho, wo, xb.ptr, yb.ptr))
+        return DeviceView(xb, (B, ho, wo, cs - 1)), DeviceView(yb, (B, ho, wo))
 
     # ---- data parallel ----------------------------------------------------------------------------------------
     @staticmethod

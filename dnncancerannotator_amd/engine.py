@@ -19,7 +19,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import device, distributed, losses as custom_losses, metrics as custom_metrics, models
+from . import augment, device, distributed, losses as custom_losses, metrics as custom_metrics, models
 
 
 class History:
@@ -182,14 +182,21 @@ class TFKerasModel:
         t0 = time.time()
         while max_steps is None or step < max_steps:
             try:
-                x, y = next(it)
+                batch = next(it)
             except StopIteration:
                 logging.warning('dataset exhausted at step %d', step)
                 break
-            x, y = self._shard(np.asarray(x), np.asarray(y))
             if schedule is not None:
                 self.learning_rate = float(schedule(step, self.learning_rate))
-            out = dm.train_step(x, y, self.learning_rate, cfg)
+            if isinstance(batch, augment.RawBatch):
+                # uint8 slices + their random draws: crop / flip / contrast / 255 / feature-label split on the device
+                raw, _ = self._shard(batch.raw)
+                params, _ = self._shard(batch.params)
+                xb, yb = dm.augment_u8(raw, params, batch.output_size, batch.label_index)
+                out = dm.train_step_dev(xb, yb, len(raw), self.learning_rate, cfg, want_out=True)
+            else:
+                x, y = self._shard(np.asarray(batch[0]), np.asarray(batch[1]))
+                out = dm.train_step(x, y, self.learning_rate, cfg)
             step += 1
             self.current_step = step
             logs = dict(loss=float(out.loss), lr=self.learning_rate)

@@ -6,10 +6,10 @@ from .. import data, dump, engine, load
 
 
 def make_dataset(paths, options, training):
-    """Dataset for `--data_path`.  Supported sources: the reference's `.tfrecords` exam files (tfrecord.py: centre crop, /255,
-    label split -- no augmentation), `synthetic[:HxW[xC]]` (seeded synthetic slices) and `.npz` files holding `x` [N,H,W,C]
-    in [0,1] and `y` [N,H,W].  The image-folder pipeline and the augmentations (data.py:538-763) run on TensorFlow and are
-    outside the accelerated hot path."""
+    """Dataset for `--data_path`.  Supported sources: the reference's `.tfrecords` exam files (tfrecord.py; for training with the
+    `augment_options` of data_options.train -- random crop / flip / contrast run on the device, random_warp is skipped),
+    `synthetic[:HxW[xC]]` (seeded synthetic slices) and `.npz` files holding `x` [N,H,W,C] in [0,1] and `y` [N,H,W].
+    The image-folder pipeline (data.py:170-180) is outside the accelerated hot path."""
     batch_size = options.get('batch_size', 8)
     first = paths[0]
     if first.startswith('synthetic'):
@@ -20,8 +20,13 @@ def make_dataset(paths, options, training):
     if all(p.endswith('.tfrecords') for p in paths):          # the reference's exam files (data.py:166-169)
         from ..tfrecord import TFRecordDataset
         slice_types = options.get('slice_types', ['TRA', 'ADC', 'DWI', 'DCEE', 'DCEL', 'label'])
-        return TFRecordDataset(paths, slice_types, batch_size, output_size=tuple(options.get('output_size', (512, 512))),
-                               repeat=training, drop_remainder=training)
+        # train_ds (data.py:62-111): output_size defaults to 256 x 256 and there is always at least the random crop;
+        # eval_ds (data.py:114-143): centre crop to output_size (default 512 x 512), no augmentation
+        return TFRecordDataset(paths, slice_types, batch_size,
+                               output_size=tuple(options.get('output_size', (256, 256) if training else (512, 512))),
+                               repeat=training, drop_remainder=training,
+                               augment_options=options.get('augment_options') if training else False,
+                               buffer_size=options.get('buffer_size', 0) if training else 0)
     if all(p.endswith('.npz') for p in paths):
         import numpy as np
         xs, ys = zip(*((z['x'], z['y']) for z in map(np.load, paths)))

@@ -236,11 +236,20 @@ def read_exams(path, output_slice_types=None):
 
 
 class TFRecordDataset:
-    """Batches (x float32 [B, H, W, C] in [0, 1], y float32 [B, H, W]) from the reference's .tfrecords exam files:
-    centre crop to `output_size` (data.py:195-200), /255 (data.py:205-206), `label` channel -> y, the remaining channels ->
-    x in `slice_types` order (data.py:766-788).  Augmentations (data.py:538-763) are TensorFlow-side and not reproduced."""
+    """Batches from the reference's .tfrecords exam files.
 
-    def __init__(self, paths, slice_types, batch_size, output_size=(512, 512), repeat=False, drop_remainder=False, **ignored):
+    Evaluation (`augment_options` False): (x float32 [B, H, W, C] in [0, 1], y float32 [B, H, W]) -- centre crop to `output_size`
+    (data.py:195-200), /255 (data.py:205-206), `label` channel -> y, the remaining channels -> x in `slice_types` order
+    (data.py:766-788), all on the host.
+
+    Training (`augment_options` a dict or None, data.py:62-111 train_ds): the slices are centre-cropped to 512 x 512 (the `base`
+    call of train_ds, data.py:95-100), shuffled through a buffer of `buffer_size` slices (data.py:106) and handed on as uint8
+    `augment.RawBatch`es with their random draws; crop / flip / contrast / the /255 and the feature-label split then run on the
+    device (`dnnca_augment_u8`, engine.train).  random_warp is skipped (augment.py)."""
+
+    def __init__(self, paths, slice_types, batch_size, output_size=(512, 512), repeat=False, drop_remainder=False,
+                 augment_options=False, buffer_size=0, seed=0, **ignored):
+        from . import augment
         self.paths = list(paths)
         self.slice_types = list(slice_types)
         assert 'label' in self.slice_types, 'slice_types must name the label channel (data.py:771)'
@@ -248,29 +257,78 @@ class TFRecordDataset:
         self.repeat, self.drop_remainder = repeat, drop_remainder
         self.feature_idx = [i for i, t in enumerate(self.slice_types) if t != 'label']
         self.label_idx = self.slice_types.index('label')
+        self.plan = None if augment_options is False else augment.parse_augment_options(augment_options, self.output_size)
+        if self.plan is not None:
+            self.output_size = self.plan.output_size
+        self.buffer_size = int(buffer_size)
+        self.rng = np.random.default_rng(seed)
         self.element_spec = (Spec((self.batch_size,) + self.output_size + (len(self.feature_idx),), np.float32),
                              Spec((self.batch_size,) + self.output_size, np.float32))
+
+    @staticmethod
+    def _centre(s, oh, ow):
+        gy, gx = (s.shape[1] - oh) // 2, (s.shape[2] - ow) // 2
+        return s[:, gy:gy + oh, gx:gx + ow, :]
+
+    def _raw_slices(self):
+        """uint8 [H, W, Cs] slices in file order, centre-cropped like train_ds's base() call (512 x 512, data.py:97)."""
+        for path in self.paths:
+            for exam in read_exams(path, self.slice_types):
+                s = exam.slices
+                s = self._centre(s, min(512, s.shape[1]), min(512, s.shape[2]))
+                for k in range(len(s)):
+                    yield s[k]
+
+    def _shuffled(self, it):
+        """tf.data shuffle(buffer_size): fill a buffer, then emit a random element and replace it with the next one."""
+        if self.buffer_size <= 1:
+            yield from it
+            return
+        buf = []
+        for el in it:
+            if len(buf) < self.buffer_size:
+                buf.append(el)
+                continue
+            k = int(self.rng.integers(len(buf)))
+            out, buf[k] = buf[k], el
+            yield out
+        while buf:
+            k = int(self.rng.integers(len(buf)))
+            buf[k], buf[-1] = buf[-1], buf[k]
+            yield buf.pop()
 
     def _slices(self):
         oh, ow = self.output_size
         for path in self.paths:
             for exam in read_exams(path, self.slice_types):
-                s = exam.slices
-                gy, gx = (s.shape[1] - oh) // 2, (s.shape[2] - ow) // 2
-                s = s[:, gy:gy + oh, gx:gx + ow, :].astype(np.float32) / np.float32(255.0)
+                s = self._centre(exam.slices, oh, ow).astype(np.float32) / np.float32(255.0)
                 for k in range(len(s)):
                     yield s[k][..., self.feature_idx], s[k][..., self.label_idx]
 
+    def _augmented(self):
+        from . import augment
+        raws = []
+        for r in self._shuffled(self._raw_slices()):
+            raws.append(r)
+            if len(raws) == self.batch_size:
+                yield augment.RawBatch(np.stack(raws), augment.draw_params(self.rng, len(raws), self.plan), self.output_size, self.label_idx)
+                raws = []
+        if raws and not self.drop_remainder:
+            yield augment.RawBatch(np.stack(raws), augment.draw_params(self.rng, len(raws), self.plan), self.output_size, self.label_idx)
+
     def __iter__(self):
         while True:
-            xs, ys = [], []
-            for x, y in self._slices():
-                xs.append(x)
-                ys.append(y)
-                if len(xs) == self.batch_size:
+            if self.plan is not None:
+                yield from self._augmented()
+            else:
+                xs, ys = [], []
+                for x, y in self._slices():
+                    xs.append(x)
+                    ys.append(y)
+                    if len(xs) == self.batch_size:
+                        yield np.stack(xs), np.stack(ys)
+                        xs, ys = [], []
+                if xs and not self.drop_remainder:
                     yield np.stack(xs), np.stack(ys)
-                    xs, ys = [], []
-            if xs and not self.drop_remainder:
-                yield np.stack(xs), np.stack(ys)
             if not self.repeat:
                 return

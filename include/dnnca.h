@@ -124,6 +124,17 @@ int dnnca_dev_alloc(void** dev_ptr, size_t bytes);
 int dnnca_dev_free(void* dev_ptr);
 int dnnca_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 int dnnca_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
+/* ---- train-time augmentation on the device (annotator/data.py:62-111 train_ds): crop + flip + contrast + feature/label split
+   of a uint8 batch [batch, hs, ws, cs] resident in HBM (upload it with dnnca_memcpy_h2d as stored in the TFRecords), written as
+   x [batch, ho, wo, cs-1] and y [batch, ho, wo] float32.  Per image the host passes its random draws:
+     dy, dx    crop jitter added to the centre offsets (data.py:677-689 random_crop: clip(int(N(0, 4)), -6, 6))
+     flip      1 = tf.image.random_flip_left_right took the flip branch (data.py:620-625)
+     contrast  factor of tf.image.random_contrast, U[0.8, 1.2) (data.py:586-609); applied to the source channels whose bit is
+               set in contrast_mask (never to the label channel); 1.0 = identity
+   Fails with DNNCA_EINVAL when a crop window leaves the source image (tf.image.crop_to_bounding_box asserts the same). */
+typedef struct { int32_t dy, dx, flip; float contrast; } dnnca_aug_param;
+int dnnca_augment_u8(void* model, const void* src_dev, int batch, int hs, int ws, int cs, int label_index, unsigned contrast_mask,
+                     const dnnca_aug_param* params_host, int ho, int wo, float* x_dev, float* y_dev);
 /* same as dnnca_train_step with x/y already in HBM; asynchronous on the model's stream; out may be NULL (no sync) */
 int dnnca_train_step_dev(void* model, const float* x_dev, const float* y_dev, int batch, float lr,
                          const dnnca_loss_cfg* cfg, dnnca_step_out* out);

@@ -262,9 +262,9 @@ def test_cli_train_then_evaluate_on_tfrecords(gpu, tmp_path):
     types = ['TRA', 'ADC', 'DWI', 'label']
     exams = []
     for i in range(2):
-        s = rng.integers(0, 256, (4, 40, 40, 4), dtype=np.uint8)
+        s = rng.integers(0, 256, (4, 48, 48, 4), dtype=np.uint8)     # 8 px of margin: the training crop jitters by up to 6
         s[..., 3] = 0
-        s[:, 10:20, 12:22, 3] = 255
+        s[:, 14:24, 16:26, 3] = 255
         exams.append(T.make_example(s, i, i, '/e/%d' % i, 'cancer', types))
     rec = str(tmp_path / 'exams.tfrecords')
     T.write_records(rec, exams)
