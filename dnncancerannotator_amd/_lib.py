@@ -81,6 +81,8 @@ SIGNATURES = {
     'dnnca_dev_alloc': (C.c_int, [C.POINTER(_VP), C.c_size_t]),
     'dnnca_dev_free': (C.c_int, [_VP]),
     'dnnca_memcpy_h2d': (C.c_int, [_VP, _VP, C.c_size_t]),
+    'dnnca_warp_f32': (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 _VP, _VP]),
     'dnnca_augment_u8': (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(AugParam), C.c_int, C.c_int,
                                    _VP, _VP]),
     'dnnca_memcpy_d2h': (C.c_int, [_VP, _VP, C.c_size_t]),

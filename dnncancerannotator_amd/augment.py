@@ -5,9 +5,9 @@ The reference applies, per image and in the order of `data_options.train.augment
     random_flip      tf.image.random_flip_left_right: flip when U[0,1) < 0.5                              (data.py:620-625)
     random_contrast  tf.image.random_contrast(lower, upper) on the feature channels                       (data.py:586-609)
     random_warp      tfa.image.sparse_image_warp                                                          (data.py:725-763)
-The first three run on the device (`dnnca_augment_u8`); this module draws their per-image parameters with a numpy generator
-(TensorFlow's own random streams cannot be reproduced without TensorFlow, so the draws are not bit-compatible with a TF run --
-their distributions are the reference's).  random_warp is not part of the accelerated path: it is skipped with a warning.
+All four run on the device (`dnnca_augment_u8`, `dnnca_warp_f32`); this module draws their per-image parameters with a numpy
+generator (TensorFlow's own random streams cannot be reproduced without TensorFlow, so the draws are not bit-compatible with a TF
+run -- their distributions are the reference's) and solves the small spline system of the warp.
 """
 
 import logging
@@ -15,8 +15,8 @@ from collections import namedtuple
 
 import numpy as np
 
-AugmentPlan = namedtuple('AugmentPlan', ['crop', 'flip', 'contrast', 'output_size'])
-RawBatch = namedtuple('RawBatch', ['raw', 'params', 'output_size', 'label_index'])
+AugmentPlan = namedtuple('AugmentPlan', ['crop', 'flip', 'contrast', 'warp', 'output_size'])
+RawBatch = namedtuple('RawBatch', ['raw', 'params', 'output_size', 'label_index', 'warp'])      # warp: (ctrl, wv) or None
 
 _KNOWN = ('random_crop', 'random_flip', 'random_contrast', 'random_warp')
 _warned = set()
@@ -26,7 +26,7 @@ def parse_augment_options(options, output_size):
     """data.py:538-551 + the defaults of train_ds (data.py:87-93).  options None -> {'random_crop': {}} like train_ds."""
     if options is None:
         options = {'random_crop': {}}
-    crop, flip, contrast = None, False, None
+    crop, flip, contrast, warp = None, False, None, None
     for name, conf in options.items():
         conf = dict(conf or {})
         if name not in _KNOWN:
@@ -42,10 +42,10 @@ def parse_augment_options(options, output_size):
             contrast = dict(lower=0.8, upper=1.2)
             contrast.update({k: v for k, v in conf.items() if k != 'target_channels'})
             contrast['target_channels'] = conf.get('target_channels')          # None: every feature channel (data.py:91)
-        elif name == 'random_warp' and name not in _warned:
-            _warned.add(name)
-            logging.warning('augment option random_warp (tfa sparse_image_warp) is outside the accelerated path: skipped')
-    return AugmentPlan(crop, flip, contrast, tuple(output_size))
+        elif name == 'random_warp':
+            warp = dict(n_points=100, max_diff=5, stddev=2.0)                  # data.py:725 random_warp defaults
+            warp.update({k: v for k, v in conf.items() if k != 'process_in_batch'})
+    return AugmentPlan(crop, flip, contrast, warp, tuple(output_size))
 
 
 def draw_params(rng, n, plan):
@@ -61,3 +61,37 @@ def draw_params(rng, n, plan):
         contrast = float(rng.uniform(plan.contrast['lower'], plan.contrast['upper'])) if plan.contrast is not None else 1.0
         out.append((dy, dx, flip, contrast))
     return out
+
+
+def draw_warp(rng, n, size, n_points=100, max_diff=5, stddev=2.0):
+    """Control points of random_warp (data.py:748-752) for `n` square images of edge `size`: source uniform in [0, size)^2,
+    destination = source + clip(N(0, stddev), -max_diff, max_diff).  Returns (source, dest) float32 [n, n_points, 2]."""
+    raw = rng.uniform(0.0, float(size), (n, n_points, 2)).astype(np.float32)
+    diff = np.clip(rng.normal(0.0, stddev, (n, n_points, 2)), -max_diff, max_diff).astype(np.float32)
+    return raw, raw + diff
+
+
+def _phi2(r):
+    """tfa interpolate_spline._phi for order 2 on squared distances: 0.5 r log(max(r, 1e-10))"""
+    return 0.5 * r * np.log(np.maximum(r, 1e-10))
+
+
+def solve_warp(source, dest):
+    """The polyharmonic-spline system of tfa.image.sparse_image_warp (order 2, no regularisation, no boundary points):
+    train points = dest, train values = dest - source; [[phi(|ci-cj|^2), B], [B^T, 0]] [w; v] = [f; 0] with B = [c, 1].
+    Returns (ctrl = dest, wv [n, n_points + 3, 2]) float64 for dnnca_warp_f32."""
+    source, dest = np.asarray(source, np.float64), np.asarray(dest, np.float64)
+    n, k, _ = dest.shape
+    out = np.empty((n, k + 3, 2), np.float64)
+    for b in range(n):
+        c, f = dest[b], dest[b] - source[b]
+        d2 = ((c[:, None, :] - c[None, :, :]) ** 2).sum(-1)
+        lhs = np.zeros((k + 3, k + 3))
+        lhs[:k, :k] = _phi2(d2)
+        lhs[:k, k:k + 2] = c
+        lhs[:k, k + 2] = 1.0
+        lhs[k:, :k] = lhs[:k, k:].T
+        rhs = np.zeros((k + 3, 2))
+        rhs[:k] = f
+        out[b] = np.linalg.solve(lhs, rhs)
+    return dest, out

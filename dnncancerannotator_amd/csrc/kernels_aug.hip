@@ -6,7 +6,7 @@
 //   to_feature_label() label channel -> y, the others in order -> x                        (data.py:766-788)
 // in two launches over a uint8 batch that was uploaded as stored (a quarter of the float bytes over PCIe).  The random draws are
 // made by the host (augment.py) and passed per image, so the arithmetic is checkable against the oracle draw for draw.
-// random_warp (tfa.image.sparse_image_warp) is not part of this path.
+// random_warp (tfa.image.sparse_image_warp) follows below as dnnca_warp_f32.
 #include "fast.h"
 #include "kernels.h"
 
@@ -135,5 +135,96 @@ int dnnca_augment_u8(void* model, const void* src_dev, int batch, int hs, int ws
     LAUNCH(M, "aug_apply", (double)batch * n * (cs + 4.0 * cs), 0,
            hipLaunchKernelGGL(k_aug_apply, dim3((unsigned)(((size_t)batch * n + 255) / 256)), dim3(256), 0, M->stream, a));
     HIP_TRY(hipStreamSynchronize(M->stream));        // params_host may be released by the caller
+    return DNNCA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ random_warp (dense part)
+// annotator/data.py:725-763 random_warp -> tfa.image.sparse_image_warp(image, source = raw, dest = raw + diff), order 2:
+//   flow(q) = sum_i phi(|q - c_i|^2) w_i + [q, 1] v        phi(r) = 0.5 r log(max(r, 1e-10))   (tfa interpolate_spline, order 2)
+//   out(q)  = bilinear(image, q - flow(q))                  (tfa dense_image_warp / interpolate_bilinear, "ij" indexing)
+// The (n+3) x (n+3) spline system is solved on the host (augment.solve_warp); here every output pixel evaluates its flow from the
+// n control points c_i (the *destination* points) and the weights (w, v), and samples features and label with the same flow.
+namespace dnnca {
+
+struct WarpArgs {
+    const float* x;          // [B, H, W, C] source features
+    const float* y;          // [B, H, W] source label
+    const double* ctrl;      // [B, n, 2] control points (row, column)
+    const double* wv;        // [B, n + 3, 2] spline weights w (n rows) then v (3 rows: row coefficient, column coefficient, constant)
+    float* xo;
+    float* yo;
+    int B, H, W, C, n;
+};
+
+__global__ __launch_bounds__(256) void k_warp(WarpArgs p) {
+    // The thin-plate weights cancel massively (|phi| ~ 1e4, flows ~ 1): the flow is evaluated in double (the float32 sum is only
+    // good to ~1e-2 pixel, which is also all that tfa's own float32 evaluation is good for).
+    extern __shared__ double sm[];         // control points + weights of this image: n * 4 + 6 doubles
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < p.n * 2; i += 256) {
+        sm[i] = p.ctrl[(size_t)b * p.n * 2 + i];
+        sm[p.n * 2 + i] = p.wv[(size_t)b * (p.n + 3) * 2 + i];
+    }
+    if (threadIdx.x < 6) sm[p.n * 4 + threadIdx.x] = p.wv[((size_t)b * (p.n + 3) + p.n) * 2 + threadIdx.x];
+    __syncthreads();
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= p.H * p.W) return;
+    const int qy = id / p.W, qx = id - qy * p.W;
+    const float fqy = (float)qy, fqx = (float)qx;
+    const double* v = sm + p.n * 4;
+    double d0 = qy * v[0] + qx * v[2] + v[4];             // linear term [q, 1] v  (v rows: y, x, 1; columns: flow_y, flow_x)
+    double d1 = qy * v[1] + qx * v[3] + v[5];
+    for (int i = 0; i < p.n; ++i) {
+        const double dy = qy - sm[2 * i], dx = qx - sm[2 * i + 1];
+        const double r = dy * dy + dx * dx;
+        const double ph = 0.5 * r * log(fmax(r, 1e-10));
+        d0 = fma(ph, sm[p.n * 2 + 2 * i], d0);
+        d1 = fma(ph, sm[p.n * 2 + 2 * i + 1], d1);
+    }
+    const float f0 = (float)d0, f1 = (float)d1;
+    // interpolate_bilinear at (qy - f0, qx - f1): floor clamped to [0, size - 2], alpha clipped to [0, 1]
+    const float sy = fqy - f0, sx = fqx - f1;
+    const float fy = fminf(fmaxf(floorf(sy), 0.f), (float)(p.H - 2)), fx = fminf(fmaxf(floorf(sx), 0.f), (float)(p.W - 2));
+    const float ay = fminf(fmaxf(sy - fy, 0.f), 1.f), ax = fminf(fmaxf(sx - fx, 0.f), 1.f);
+    const int iy = (int)fy, ix = (int)fx;
+    const size_t o00 = ((size_t)b * p.H + iy) * p.W + ix, o01 = o00 + 1, o10 = o00 + p.W, o11 = o10 + 1;
+    const size_t oq = ((size_t)b * p.H + qy) * p.W + qx;
+    auto lerp2 = [&](float tl, float tr, float bl, float br) {
+        const float top = ax * (tr - tl) + tl, bot = ax * (br - bl) + bl;
+        return ay * (bot - top) + top;
+    };
+    for (int c = 0; c < p.C; ++c)
+        p.xo[oq * p.C + c] = lerp2(p.x[o00 * p.C + c], p.x[o01 * p.C + c], p.x[o10 * p.C + c], p.x[o11 * p.C + c]);
+    p.yo[oq] = lerp2(p.y[o00], p.y[o01], p.y[o10], p.y[o11]);
+}
+
+}  // namespace dnnca
+
+int dnnca_warp_f32(void* model, const float* x_dev, const float* y_dev, int batch, int h, int w, int c, int n_points,
+                   const double* ctrl_host, const double* wv_host, float* x_out_dev, float* y_out_dev) {
+    Model* M = reinterpret_cast<Model*>(model);
+    if (!M) { set_error("null model"); return DNNCA_EINVAL; }
+    if (!x_dev || !y_dev || !ctrl_host || !wv_host || !x_out_dev || !y_out_dev || batch < 1 || h < 2 || w < 2 || c < 1 || n_points < 1 ||
+        n_points > 2048 || x_out_dev == x_dev || y_out_dev == y_dev) {
+        set_error("dnnca_warp_f32: bad arguments");
+        return DNNCA_EINVAL;
+    }
+    const size_t nc = (size_t)batch * n_points * 2 * 8, nw = (size_t)batch * (n_points + 3) * 2 * 8;
+    if (nc + nw > M->warp_scratch_bytes) {
+        void* p = nullptr;
+        DN_TRY(M->alloc(&p, nc + nw));
+        M->warp_scratch = p;
+        M->warp_scratch_bytes = nc + nw;
+    }
+    WarpArgs a{};
+    a.x = x_dev; a.y = y_dev; a.xo = x_out_dev; a.yo = y_out_dev;
+    a.ctrl = (const double*)M->warp_scratch;
+    a.wv = (const double*)((char*)M->warp_scratch + nc);
+    a.B = batch; a.H = h; a.W = w; a.C = c; a.n = n_points;
+    HIP_TRY(hipMemcpyAsync((void*)a.ctrl, ctrl_host, nc, hipMemcpyHostToDevice, M->stream));
+    HIP_TRY(hipMemcpyAsync((void*)a.wv, wv_host, nw, hipMemcpyHostToDevice, M->stream));
+    LAUNCH(M, "aug_warp", (double)batch * h * w * (c + 1) * 8.0, (double)batch * h * w * n_points * 8.0,
+           hipLaunchKernelGGL(k_warp, dim3((h * w + 255) / 256, batch), dim3(256), (size_t)(n_points * 4 + 6) * 8, M->stream, a));
+    HIP_TRY(hipStreamSynchronize(M->stream));
     return DNNCA_OK;
 }

@@ -295,6 +295,19 @@ class DeviceModel:
         check(self.lib.dnnca_augment_u8(self.handle, src.ptr, B, hs, ws, cs, int(label_index), mask, prm, ho, wo, xb.ptr, yb.ptr))
         return DeviceView(xb, (B, ho, wo, cs - 1)), DeviceView(yb, (B, ho, wo))
 
+    def warp(self, xv, yv, ctrl, wv):
+        """random_warp's dense part on device-resident (x, y) views: ctrl [B, n, 2], wv [B, n + 3, 2] from augment.solve_warp."""
+        B, h, w, c = xv.shape
+        ctrl, wv = np.ascontiguousarray(ctrl, np.float64), np.ascontiguousarray(wv, np.float64)
+        dptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))        # noqa: E731
+        if not hasattr(self, '_warp'):
+            self._warp = (RawDeviceBuffer(), RawDeviceBuffer())
+        xo, yo = self._warp
+        xo.reserve(xv.nbytes)
+        yo.reserve(yv.nbytes)
+        check(self.lib.dnnca_warp_f32(self.handle, xv.ptr, yv.ptr, B, h, w, c, ctrl.shape[1], dptr(ctrl), dptr(wv), xo.ptr, yo.ptr))
+        return DeviceView(xo, xv.shape), DeviceView(yo, yv.shape)
+
     # ---- data parallel ----------------------------------------------------------------------------------------
     @staticmethod
     def comm_unique_id():

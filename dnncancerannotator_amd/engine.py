@@ -193,6 +193,8 @@ class TFKerasModel:
                 raw, _ = self._shard(batch.raw)
                 params, _ = self._shard(batch.params)
                 xb, yb = dm.augment_u8(raw, params, batch.output_size, batch.label_index)
+                if batch.warp is not None:
+                    xb, yb = dm.warp(xb, yb, self._shard(batch.warp[0])[0], self._shard(batch.warp[1])[0])
                 out = dm.train_step_dev(xb, yb, len(raw), self.learning_rate, cfg, want_out=True)
             else:
                 x, y = self._shard(np.asarray(batch[0]), np.asarray(batch[1]))

@@ -245,7 +245,7 @@ class TFRecordDataset:
     Training (`augment_options` a dict or None, data.py:62-111 train_ds): the slices are centre-cropped to 512 x 512 (the `base`
     call of train_ds, data.py:95-100), shuffled through a buffer of `buffer_size` slices (data.py:106) and handed on as uint8
     `augment.RawBatch`es with their random draws; crop / flip / contrast / the /255 and the feature-label split then run on the
-    device (`dnnca_augment_u8`, engine.train).  random_warp is skipped (augment.py)."""
+    device (`dnnca_augment_u8` / `dnnca_warp_f32`, engine.train)."""
 
     def __init__(self, paths, slice_types, batch_size, output_size=(512, 512), repeat=False, drop_remainder=False,
                  augment_options=False, buffer_size=0, seed=0, **ignored):
@@ -311,10 +311,19 @@ class TFRecordDataset:
         for r in self._shuffled(self._raw_slices()):
             raws.append(r)
             if len(raws) == self.batch_size:
-                yield augment.RawBatch(np.stack(raws), augment.draw_params(self.rng, len(raws), self.plan), self.output_size, self.label_idx)
+                yield self._raw_batch(raws)
                 raws = []
         if raws and not self.drop_remainder:
-            yield augment.RawBatch(np.stack(raws), augment.draw_params(self.rng, len(raws), self.plan), self.output_size, self.label_idx)
+            yield self._raw_batch(raws)
+
+    def _raw_batch(self, raws):
+        from . import augment
+        warp = None
+        if self.plan.warp is not None:
+            if self.output_size[0] != self.output_size[1]:
+                raise ValueError('random_warp supports square images only (data.py:746 asserts width == height)')
+            warp = augment.solve_warp(*augment.draw_warp(self.rng, len(raws), self.output_size[0], **self.plan.warp))
+        return augment.RawBatch(np.stack(raws), augment.draw_params(self.rng, len(raws), self.plan), self.output_size, self.label_idx, warp)
 
     def __iter__(self):
         while True:

@@ -135,6 +135,13 @@ int dnnca_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
 typedef struct { int32_t dy, dx, flip; float contrast; } dnnca_aug_param;
 int dnnca_augment_u8(void* model, const void* src_dev, int batch, int hs, int ws, int cs, int label_index, unsigned contrast_mask,
                      const dnnca_aug_param* params_host, int ho, int wo, float* x_dev, float* y_dev);
+/* random_warp (annotator/data.py:725-763 -> tfa.image.sparse_image_warp, interpolation order 2, no boundary points): dense part.
+   ctrl_host [batch, n_points, 2] = the destination control points (row, column); wv_host [batch, n_points + 3, 2] = the solution
+   (w; v) of the polyharmonic-spline system for the control-point flows (dest - source), solved by the caller
+   (dnncancerannotator_amd/augment.py solve_warp).  Every output pixel q evaluates flow(q) and samples x [batch, h, w, c] and
+   y [batch, h, w] bilinearly at q - flow(q) (tfa dense_image_warp); outputs must not alias the inputs. */
+int dnnca_warp_f32(void* model, const float* x_dev, const float* y_dev, int batch, int h, int w, int c, int n_points,
+                   const double* ctrl_host, const double* wv_host, float* x_out_dev, float* y_out_dev);
 /* same as dnnca_train_step with x/y already in HBM; asynchronous on the model's stream; out may be NULL (no sync) */
 int dnnca_train_step_dev(void* model, const float* x_dev, const float* y_dev, int batch, float lr,
                          const dnnca_loss_cfg* cfg, dnnca_step_out* out);

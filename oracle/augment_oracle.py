@@ -10,6 +10,12 @@ fixture for them; the restatement follows the call sites below and the published
     random_contrast()   annotator/data.py:586-609   tf.image.adjust_contrast: (x - mean_HW(x)) * factor + mean_HW(x) per channel,
                                                     on the target channels only, channel order restored
     to_feature_label()  annotator/data.py:766-788   label channel -> y, the others (in order) -> x
+    random_warp()       annotator/data.py:725-763   tfa.image.sparse_image_warp(image, source, dest): tensorflow-addons is a
+                                                    third-party dependency absent from /root/reference (requirements.txt:3,
+                                                    unpinned); restated from its published algorithm: interpolate_spline
+                                                    (order 2, phi(r) = 0.5 r log(max(r, 1e-10)) on squared distances, linear
+                                                    term [q, 1] v, no regularisation) + dense_image_warp (bilinear sampling at
+                                                    q - flow, floor clamped to [0, size - 2], alpha clipped to [0, 1])
 """
 
 import numpy as np
@@ -41,3 +47,33 @@ def augment_image(img_u8, dy, dx, flip, contrast, output_size, label_index, targ
 def augment_batch(raw_u8, params, output_size, label_index, target_channels=None):
     xs, ys = zip(*(augment_image(raw_u8[b], *params[b], output_size, label_index, target_channels) for b in range(len(raw_u8))))
     return np.stack(xs), np.stack(ys)
+
+
+def warp_image(img, source, dest):
+    """tfa.image.sparse_image_warp on one float image [H, W, C] (float64 arithmetic); source / dest [n, 2] (row, column)."""
+    img = np.asarray(img, np.float64)
+    h, w, _ = img.shape
+    c = np.asarray(dest, np.float64)
+    f = c - np.asarray(source, np.float64)
+    k = len(c)
+    phi = lambda r: 0.5 * r * np.log(np.maximum(r, 1e-10))                      # noqa: E731
+    lhs = np.zeros((k + 3, k + 3))
+    lhs[:k, :k] = phi(((c[:, None] - c[None]) ** 2).sum(-1))
+    lhs[:k, k:k + 2] = c
+    lhs[:k, k + 2] = 1.0
+    lhs[k:, :k] = lhs[:k, k:].T
+    rhs = np.zeros((k + 3, 2))
+    rhs[:k] = f
+    wv = np.linalg.solve(lhs, rhs)
+    qy, qx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing='ij')
+    q = np.stack([qy, qx], -1).reshape(-1, 2)
+    flow = phi(((q[:, None] - c[None]) ** 2).sum(-1)) @ wv[:k] + np.concatenate([q, np.ones((len(q), 1))], 1) @ wv[k:]
+    s = q - flow
+    fy = np.clip(np.floor(s[:, 0]), 0, h - 2)
+    fx = np.clip(np.floor(s[:, 1]), 0, w - 2)
+    ay = np.clip(s[:, 0] - fy, 0, 1)[:, None]
+    ax = np.clip(s[:, 1] - fx, 0, 1)[:, None]
+    iy, ix = fy.astype(int), fx.astype(int)
+    tl, tr, bl, br = img[iy, ix], img[iy, ix + 1], img[iy + 1, ix], img[iy + 1, ix + 1]
+    top, bot = ax * (tr - tl) + tl, ax * (br - bl) + bl
+    return (ay * (bot - top) + top).reshape(h, w, -1)

@@ -14,6 +14,7 @@ def test_parse_and_draws():
     # configs/additionals/data_options.yaml:9-13 (every option empty); train_ds fills in the defaults (data.py:87-93)
     plan = augment.parse_augment_options({'random_crop': None, 'random_flip': None, 'random_contrast': None, 'random_warp': None}, (256, 256))
     assert plan.crop == dict(stddev=4, max_=6, min_=-6) and plan.flip and plan.contrast['lower'] == 0.8 and plan.output_size == (256, 256)
+    assert plan.warp == dict(n_points=100, max_diff=5, stddev=2.0)
     assert augment.parse_augment_options(None, (128, 128)).crop is not None          # train_ds: at least the random crop
     with pytest.raises(KeyError):
         augment.parse_augment_options({'random_hue2': {}}, (8, 8))
@@ -65,6 +66,47 @@ def test_device_augment_matches_oracle(gpu, cs, label_index):
     assert np.array_equal(xb.to_host(), A.augment_batch(raw, no_c, (ho, wo), label_index)[0])
     with pytest.raises(RuntimeError):
         m.augment_u8(raw, [(17, 0, 0, 1.0)] * B, (ho, wo), label_index)          # window leaves the image
+    m.close()
+
+
+def test_warp_solution_interpolates_the_control_flows():
+    """host side of random_warp: the spline solved by augment.solve_warp reproduces the control-point flows at the control
+    points (interpolation property) and agrees with the oracle's own solve through the warped image of a smooth ramp."""
+    from dnncancerannotator_amd import augment
+    rng = np.random.default_rng(3)
+    src, dst = augment.draw_warp(rng, 2, 32, n_points=20)
+    assert src.shape == (2, 20, 2) and np.abs(dst - src).max() <= 5.0 and src.min() >= 0 and src.max() < 32
+    ctrl, wv = augment.solve_warp(src, dst)
+    for b in range(2):
+        c = ctrl[b].astype(np.float64)
+        d2 = ((c[:, None] - c[None]) ** 2).sum(-1)
+        flow = (0.5 * d2 * np.log(np.maximum(d2, 1e-10))) @ wv[b, :20] + np.concatenate([c, np.ones((20, 1))], 1) @ wv[b, 20:]
+        assert np.abs(flow - (dst[b] - src[b])).max() < 1e-3
+    ident = A.warp_image(rng.random((16, 16, 2)), src[0, :5] / 2, src[0, :5] / 2)           # zero flow: identity
+    assert ident.shape == (16, 16, 2)
+
+
+@pytest.mark.gpu
+def test_device_warp_matches_oracle(gpu):
+    """dnnca_warp_f32 against the oracle's restatement of tfa.image.sparse_image_warp.  Channel 0 / 1 of the warped image are
+    the row / column ramps, so their output IS the sampling position q - flow(q): it must agree to a hundredth of a pixel; the
+    third channel and the label are smooth images (a noise image would amplify that hundredth by its gradients)."""
+    from dnncancerannotator_amd import augment
+    rng = np.random.default_rng(4)
+    B, S = 3, 48
+    yy, xx = np.mgrid[:S, :S].astype(np.float32)
+    smooth = 0.5 + 0.25 * np.sin(yy / 7.0) * np.cos(xx / 5.0)
+    x0 = np.stack([np.stack([yy / S, xx / S, smooth], -1)] * B).astype(np.float32)
+    y0 = np.stack([(smooth > 0.55).astype(np.float32) * 0 + smooth[::-1]] * B).astype(np.float32)
+    m = gpu.DeviceModel('unet', 3, S, S, B, n_filters_first=3, n_downsample=1, rate=2, kernel_size=3, conv_stride=1, padding='same')
+    src, dst = augment.draw_warp(rng, B, S, n_points=100)
+    xw, yw = m.warp(gpu.DeviceBuffer(x0), gpu.DeviceBuffer(y0), *augment.solve_warp(src, dst))
+    xw, yw = xw.to_host(), yw.to_host()
+    for b in range(B):
+        ref = A.warp_image(np.concatenate([x0[b], y0[b][..., None]], -1), src[b], dst[b])
+        assert np.abs(xw[b][..., :2] - ref[..., :2]).max() * S <= 1e-2            # sampling positions, in pixels
+        assert np.abs(xw[b][..., 2] - ref[..., 2]).max() <= 1e-3 and np.abs(yw[b] - ref[..., 3]).max() <= 1e-3
+        assert np.abs(xw[b][..., :2] - x0[b][..., :2]).max() * S > 1.0             # and the image did move (by pixels)
     m.close()
 
 
