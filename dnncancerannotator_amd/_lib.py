@@ -35,7 +35,8 @@ class ModelDesc(C.Structure):
 
 
 class LossCfg(C.Structure):
-    _fields_ = [('has_weight', C.c_int32), ('weight', C.c_float), ('weight_add', C.c_float), ('weight_mul', C.c_float)]
+    _fields_ = [('has_weight', C.c_int32), ('weight', C.c_float), ('weight_add', C.c_float), ('weight_mul', C.c_float),
+                ('label_smoothing', C.c_int32), ('label_smoothing_filter_size', C.c_int32), ('label_smoothing_sigma', C.c_float)]
 
 
 class StepOut(C.Structure):

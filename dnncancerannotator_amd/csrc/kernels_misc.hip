@@ -431,6 +431,56 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
     return false;
 }
 
+// ------------------------------------------------------------------------------------------------ label smoothing
+// utils/losses.py:62-67: y_true = tfa.image.gaussian_filter2d(y_true[..., None], filter_shape = k, sigma) -- REFLECT padding of
+// (k-1)/2 before / k-1-(k-1)/2 after (tf.pad REFLECT: the edge sample is not repeated), then a VALID depthwise conv with the
+// outer product of the 1-D kernel softmax(-u^2 / (2 sigma^2)), u = -k/2+1 .. k/2 (asymmetric for even k).  One thread per pixel.
+struct SmoothArgs {
+    const float* y;
+    float* out;
+    int B, H, W, k;
+    float g[16];             // normalised 1-D kernel
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {      // tf.pad REFLECT (requires pad < n)
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void k_label_smooth(SmoothArgs p) {
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)p.B * p.H * p.W) return;
+    const int x = (int)(id % p.W), y = (int)((id / p.W) % p.H);
+    const float* img = p.y + (id / ((size_t)p.H * p.W)) * ((size_t)p.H * p.W);
+    const int before = (p.k - 1) / 2;
+    float acc = 0.f;
+    for (int i = 0; i < p.k; ++i) {
+        const int yy = reflect_idx(y + i - before, p.H);
+        float row = 0.f;
+        for (int j = 0; j < p.k; ++j) row = fmaf(p.g[j], img[(size_t)yy * p.W + reflect_idx(x + j - before, p.W)], row);
+        acc = fmaf(p.g[i], row, acc);
+    }
+    p.out[id] = acc;
+}
+
+bool fast_label_smooth(Model* m, int B, int H, int W, const float* y, float* out, int k, float sigma) {
+    if (k < 1 || k > 15 || !(sigma > 0.f) || k - 1 - (k - 1) / 2 >= H || k - 1 - (k - 1) / 2 >= W) return false;
+    SmoothArgs a{};
+    a.y = y; a.out = out; a.B = B; a.H = H; a.W = W; a.k = k;
+    double g[16], sum = 0.0;
+    for (int i = 0; i < k; ++i) {
+        const double u = (double)(-(k / 2) + 1 + i);          // tf.range(-k // 2 + 1, k // 2 + 1)
+        g[i] = exp(-(u * u) / (2.0 * (double)sigma * (double)sigma));
+        sum += g[i];
+    }
+    for (int i = 0; i < k; ++i) a.g[i] = (float)(g[i] / sum);
+    const size_t n = (size_t)B * H * W;
+    LAUNCH(m, "label_smooth", 8.0 * n, 2.0 * n * k * k,
+           hipLaunchKernelGGL(k_label_smooth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, a));
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ label statistics
 // Few, fat blocks: every block ends in one atomic on the same address, and same-address atomics execute one after the
 // other at the memory side (~56 ns each, tools/micro/bn_reduce.hip) -- 64 of them cost less than the read pass, 256 more.

@@ -68,6 +68,7 @@ struct Model {
     float* out5 = nullptr;               // = g + nT : [loss, positive_rate, weight, ymin, ymax]
     float *x_stage = nullptr, *y_stage = nullptr, *logits = nullptr, *dlogits = nullptr, *prob = nullptr;
     float* thr_dev = nullptr;
+    float* y_smooth = nullptr;           // smoothed labels of the step (label_smoothing, utils/losses.py:62-67)
     void* warp_scratch = nullptr;        // control points + spline weights of dnnca_warp_f32
     size_t warp_scratch_bytes = 0;
     void* aug_scratch = nullptr;         // per-image augmentation draws + channel sums (kernels_aug.hip)

@@ -444,6 +444,15 @@ int Model::forward(const float* x_dev, int B, bool training) {
 // ---------------------------------------------------------------------------------------------- loss + backward
 int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cfg, bool backward) {
     cur_op = nullptr;
+    if (cfg.label_smoothing) {          // utils/losses.py:62-67: every later use of y_true (positive rate, assertions, loss) sees the blurred labels
+        if (!y_smooth) DN_TRY(alloc((void**)&y_smooth, (size_t)desc.max_batch * outH * outW * 4));
+        if (!fast_label_smooth(this, B, outH, outW, y_dev, y_smooth, cfg.label_smoothing_filter_size, cfg.label_smoothing_sigma)) {
+            set_error("label_smoothing: filter size %d / sigma %g not supported for %dx%d labels", cfg.label_smoothing_filter_size,
+                      (double)cfg.label_smoothing_sigma, outH, outW);
+            return DNNCA_EINVAL;
+        }
+        y_dev = y_smooth;
+    }
     const bool generic = desc.flags & 1;
     size_t npix = (size_t)B * outH * outW;
     // scalars: label sum 0, min +inf, max -inf, loss 0, l2 0

@@ -204,11 +204,14 @@ class DeviceModel:
 
     # ---- hot path ---------------------------------------------------------------------------------------------
     @staticmethod
-    def loss_cfg(weight=None, weight_add=0.0, weight_mul=1.0, **ignored):
+    def loss_cfg(weight=None, weight_add=0.0, weight_mul=1.0, label_smoothing=False, label_smoothing_filter_size=6,
+                 label_smoothing_sigma=3, **ignored):
         c = _lib.LossCfg()
         c.has_weight = 0 if weight is None else 1
         c.weight = 0.0 if weight is None else float(weight)
         c.weight_add, c.weight_mul = float(weight_add), float(weight_mul)
+        c.label_smoothing = int(bool(label_smoothing))
+        c.label_smoothing_filter_size, c.label_smoothing_sigma = int(label_smoothing_filter_size), float(label_smoothing_sigma)
         return c
 
     def _check_x(self, x):

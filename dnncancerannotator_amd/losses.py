@@ -9,9 +9,8 @@ class WeightedCrossentropy:
 
     def __init__(self, weight=None, weight_add=0.0, weight_mul=1.0, label_smoothing=False,
                  label_smoothing_filter_size=6, label_smoothing_sigma=3):
-        if label_smoothing:
-            # tfa.image.gaussian_filter2d on the labels (losses.py:62-67) is outside the accelerated path
-            raise NotImplementedError('label_smoothing is not supported by the MI355X engine (hot-path scope, SURVEY 8a a14)')
+        if label_smoothing and not (1 <= int(label_smoothing_filter_size) <= 15 and float(label_smoothing_sigma) > 0):
+            raise ValueError('label_smoothing: filter size must be in [1, 15] and sigma > 0')
         self.weight = weight
         self.weight_add = weight_add
         self.weight_mul = weight_mul
@@ -25,7 +24,10 @@ class WeightedCrossentropy:
                     label_smoothing_sigma=self.label_smoothing_sigma)
 
     def device_cfg(self):
-        return dict(weight=self.weight, weight_add=self.weight_add, weight_mul=self.weight_mul)
+        # label_smoothing (losses.py:62-67): the Gaussian blur of the labels runs on the device before the loss
+        return dict(weight=self.weight, weight_add=self.weight_add, weight_mul=self.weight_mul,
+                    label_smoothing=bool(self.label_smoothing), label_smoothing_filter_size=int(self.label_smoothing_filter_size),
+                    label_smoothing_sigma=float(self.label_smoothing_sigma))
 
 
 _REGISTRY = {'WeightedCrossentropy': WeightedCrossentropy, 'weighted_crossentropy': WeightedCrossentropy}

@@ -65,6 +65,13 @@ typedef struct dnnca_loss_cfg {
     float weight;
     float weight_add;         /* losses.py:29 */
     float weight_mul;
+    /* utils/losses.py:62-67: y_true = tfa.image.gaussian_filter2d(y_true, filter_shape, sigma) before everything else (positive
+       rate, assertions, loss): REFLECT padding of (k-1)/2 rows/columns before and k-1-(k-1)/2 after, separable kernel
+       softmax(-u^2 / (2 sigma^2)) over u = -k/2+1 .. k/2 (tensorflow-addons, absent third-party dependency: restated from its
+       published algorithm) */
+    int32_t label_smoothing;  /* 0 = off (the default, losses.py:46) */
+    int32_t label_smoothing_filter_size;
+    float label_smoothing_sigma;
 } dnnca_loss_cfg;
 
 typedef struct dnnca_step_out {

@@ -496,14 +496,38 @@ def loss_weight(label, weight=None, weight_add=0.0, weight_mul=1.0):
     return weight
 
 
-def weighted_crossentropy(label, logits, weight=None, weight_add=0.0, weight_mul=1.0):
+def gaussian_filter2d(label, filter_size=6, sigma=3.0):
+    """tfa.image.gaussian_filter2d(label[..., None], filter_shape, sigma)[..., 0] as called at utils/losses.py:64-66
+    (tensorflow-addons: third-party, absent, unpinned in requirements.txt:3; restated from its published algorithm):
+    1-D kernel softmax(-u^2 / (2 sigma^2)) over u = range(-k // 2 + 1, k // 2 + 1), 2-D kernel = outer product, REFLECT
+    padding of (k - 1) // 2 before and k - 1 - (k - 1) // 2 after, VALID correlation.  float64 arithmetic."""
+    k = int(filter_size)
+    u = np.arange(-k // 2 + 1, k // 2 + 1, dtype=np.float64)
+    g = np.exp(-(u ** 2) / (2.0 * float(sigma) ** 2))
+    g /= g.sum()
+    before = (k - 1) // 2
+    after = k - 1 - before
+    pad = np.pad(np.asarray(label, np.float64), ((0, 0), (before, after), (before, after)), mode='reflect')
+    H, W = label.shape[1:]
+    out = np.zeros(label.shape, np.float64)
+    for i in range(k):
+        for j in range(k):
+            out += g[i] * g[j] * pad[:, i:i + H, j:j + W]
+    return out
+
+
+def weighted_crossentropy(label, logits, weight=None, weight_add=0.0, weight_mul=1.0, label_smoothing=False,
+                          label_smoothing_filter_size=6, label_smoothing_sigma=3):
     """utils/losses.py:17-37 with from_logits=True: returns (per-sample loss [B], dloss_b/dlogits [B,H,W,1]).
 
     BCE-with-logits [TF semantics]: max(x,0) - x*z + log1p(exp(-|x|)); the BCE's own mean over the size-1
-    channel axis is a no-op; sample_weight = label*(w-1)+1; mean over (H, W)."""
+    channel axis is a no-op; sample_weight = label*(w-1)+1; mean over (H, W).  label_smoothing (TFWeightedCrossentropy.call,
+    utils/losses.py:62-67) blurs the labels first; the positive rate is then taken from the blurred labels."""
     dt = logits.dtype
     if label.shape[0] == 0:
         return np.zeros([0], dt), np.zeros_like(logits)
+    if label_smoothing:
+        label = gaussian_filter2d(label, label_smoothing_filter_size, label_smoothing_sigma).astype(label.dtype)
     w = loss_weight(label, weight, weight_add, weight_mul)
     z = label.astype(dt)
     mask = z * dt.type(w - 1.0) + dt.type(1.0)

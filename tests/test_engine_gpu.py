@@ -345,3 +345,29 @@ def test_rccl_one_rank_rehearsal(gpu):
     assert max(out['diff'].values()) <= max(1e-5, 4 * max(out['noise'].values())), out
     np.testing.assert_allclose(out['losses_plain'], out['losses_rccl'], rtol=1e-6)
     assert out['red'] == [1.5, -2.0]
+
+
+@pytest.mark.parametrize('force_generic', [False, True])
+def test_label_smoothing_loss_matches_oracle(gpu, force_generic):
+    """deploy_options.loss.config.label_smoothing (utils/losses.py:62-67): the labels are blurred on the device (filter 6, sigma 3,
+    REFLECT padding) before the positive rate and the loss; loss, weight and gradients against the oracle, 40 x 24 image."""
+    spec = O.ModelSpec('unet', 1, **UNET)
+    params = Hp.perturbed_params(spec, np.float64)
+    B, H, W = 2, 40, 24
+    rng = np.random.default_rng(8)
+    x = rng.random((B, H, W, 1)).astype(np.float32)
+    y = np.zeros((B, H, W), np.float32)
+    y[0, 5:15, 4:12] = 1.0
+    y[1, 30:40, 0:6] = 1.0                                    # touches two borders: the reflect padding matters
+    cfg = dict(weight_mul=3.0, label_smoothing=True, label_smoothing_filter_size=6, label_smoothing_sigma=3)
+    loss, grads, _, _ = O.loss_and_grads(spec, params, x.astype(np.float64), y, cfg, training=True)
+    m = gpu.DeviceModel('unet', 1, H, W, B, force_generic=force_generic, **UNET)
+    m.set_params(O.flatten(spec, params))
+    out = m.train_step(x, y, 0.0, m.loss_cfg(**cfg))
+    ys = O.gaussian_filter2d(y)
+    assert abs(out.positive_rate - ys.mean()) <= 1e-6 and abs(out.label_max - ys.max()) <= 1e-6
+    assert abs(out.loss - loss) <= 1e-4 * max(1.0, abs(loss))
+    assert Hp.rel_err(m.get_grads(), O.flatten(spec, grads)) <= 2e-3
+    plain = m.train_step(x, y, 0.0, m.loss_cfg(weight_mul=3.0))
+    assert abs(plain.loss - out.loss) > 1e-3                  # and it is not a no-op
+    m.close()

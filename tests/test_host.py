@@ -56,12 +56,14 @@ def test_dump_options_never_overwrites(tmp_path):
 
 def test_loss_and_model_registries():
     l = losses.get({'class_name': 'WeightedCrossentropy', 'config': {'weight_mul': 3.0}})
-    assert l.device_cfg() == dict(weight=None, weight_add=0.0, weight_mul=3.0)
+    assert l.device_cfg() == dict(weight=None, weight_add=0.0, weight_mul=3.0, label_smoothing=False, label_smoothing_filter_size=6,
+                                  label_smoothing_sigma=3.0)
     assert losses.get('weighted_crossentropy').weight_mul == 1.0
     with pytest.raises(ValueError):
         losses.get({'class_name': 'Nope'})
-    with pytest.raises(NotImplementedError):
-        losses.get({'class_name': 'WeightedCrossentropy', 'config': {'label_smoothing': True}})
+    assert losses.get({'class_name': 'WeightedCrossentropy', 'config': {'label_smoothing': True}}).device_cfg()['label_smoothing'] is True
+    with pytest.raises(ValueError):
+        losses.get({'class_name': 'WeightedCrossentropy', 'config': {'label_smoothing': True, 'label_smoothing_sigma': 0}})
     m = getattr(models, 'UNetAnnotator')(**UNET_YAML['model_options'])
     assert m.get_config()['n_filters_first'] == 3 and m.arch == 'unet'
     assert getattr(models, 'MulmoUNetAnnotator')(**UNET_YAML['model_options']).arch == 'mulmo'

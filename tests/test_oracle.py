@@ -131,3 +131,28 @@ def test_layer_properties():
     assert np.allclose(yb.mean((0, 1, 2)), 0, atol=1e-12) and np.allclose(yb.var((0, 1, 2)), x.var((0, 1, 2)) / (x.var((0, 1, 2)) + 1e-3))
     n = 2 * 8 * 8
     assert np.allclose(nv, 0.99 + 0.01 * x.var((0, 1, 2)) * n / (n - 1))        # unbiased variance into the moving average
+
+
+def test_label_smoothing_kernel_and_padding():
+    """tfa.image.gaussian_filter2d as used at utils/losses.py:64-66 (filter 6, sigma 3): the even filter's taps sit at
+    u = -2 .. 3, the kernel sums to one (a constant image stays constant) and REFLECT padding does not repeat the edge."""
+    const = np.full((1, 9, 11), 0.25)
+    assert np.allclose(O.gaussian_filter2d(const), 0.25, atol=1e-15)
+    u = np.arange(-2, 4)
+    g = np.exp(-u ** 2 / 18.0)
+    g /= g.sum()
+    imp = np.zeros((1, 16, 16))
+    imp[0, 8, 8] = 1.0
+    out = O.gaussian_filter2d(imp)
+    # out[y, x] = sum g[i] g[j] imp[y + i - 2, x + j - 2]  ->  the impulse response is g mirrored: out[8 - u, 8 - v] = g(u) g(v)
+    for a, ua in enumerate(u):
+        for b, ub in enumerate(u):
+            assert abs(out[0, 8 - ua, 8 - ub] - g[a] * g[b]) < 1e-15
+    ramp = np.arange(8.0)[None, None, :].repeat(4, 1)                           # reflect: index -1 -> 1, -2 -> 2
+    left = O.gaussian_filter2d(ramp)[0, 0, 0]
+    assert abs(left - sum(g[j] * abs(j - 2) for j in range(6))) < 1e-12
+    logits = np.zeros((1, 8, 8, 1))
+    y = np.zeros((1, 8, 8)); y[0, 2:5, 3:6] = 1.0
+    per, _ = O.weighted_crossentropy(y, logits, label_smoothing=True)
+    per0, _ = O.weighted_crossentropy(O.gaussian_filter2d(y), logits)
+    assert np.allclose(per, per0)
