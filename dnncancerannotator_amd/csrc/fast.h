@@ -28,7 +28,8 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
 // utils/losses.py:62-67 label_smoothing: Gaussian blur of the labels (false: unsupported filter size / image smaller than the pad)
 bool fast_label_smooth(Model* m, int B, int H, int W, const float* y, float* out, int k, float sigma);
 bool fast_label_stats(Model* m, size_t n, const float* y);
-bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps);
+bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps, Op* pool);   // pool: a 2x2 max-pool of the output that rides in the apply pass
+bool fast_bn_pool_fusable(const Model* m, const Op& bn, const Op& pool);
 bool fast_bn_bwd(Model* m, int B, Op& o);
 bool fast_bn_supported(const Model* m, const Op& o);
 void fast_plan_masks(Model* m);

@@ -683,6 +683,35 @@ __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* _
     *reinterpret_cast<float4*>(y + p * yps + 4 * cq) = o;
 }
 
+// BatchNorm apply + the MaxPool2D([2,2], 2) that follows it (components.py:54,59): one thread owns a 4-channel group of a 2 x 2
+// pixel window, writes the four normalised pixels and their maximum -- the pool pass never re-reads the normalised tensor.
+__global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const float* __restrict__ x, float* __restrict__ y,
+                                                            float* __restrict__ pooled, int C, int H, int W,
+                                                            const float* __restrict__ coef) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nwin4) return;
+    const int G = C / 4, cq = (int)(i % G), Wp = W / 2, Hp = H / 2;
+    const size_t wdx = i / G;                          // window index: (b * Hp + yp) * Wp + xp
+    const int xp = (int)(wdx % Wp);
+    const size_t byp = wdx / Wp;                       // b * Hp + yp
+    const size_t b = byp / Hp;
+    const int yp = (int)(byp - b * Hp);
+    const float4 sc = *reinterpret_cast<const float4*>(coef + 4 * cq), sh = *reinterpret_cast<const float4*>(coef + C + 4 * cq);
+    const size_t p00 = ((b * H + 2 * yp) * W + 2 * xp) * C + 4 * cq;
+    float4 mx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t o = p00 + ((size_t)(k >> 1) * W + (k & 1)) * C;
+        const float4 v = *reinterpret_cast<const float4*>(x + o);
+        float4 r;
+        r.x = fmaf(v.x, sc.x, sh.x); r.y = fmaf(v.y, sc.y, sh.y); r.z = fmaf(v.z, sc.z, sh.z); r.w = fmaf(v.w, sc.w, sh.w);
+        *reinterpret_cast<float4*>(y + o) = r;
+        if (k == 0) mx = r;
+        else { mx.x = fmaxf(mx.x, r.x); mx.y = fmaxf(mx.y, r.y); mx.z = fmaxf(mx.z, r.z); mx.w = fmaxf(mx.w, r.w); }
+    }
+    *reinterpret_cast<float4*>(pooled + wdx * C + 4 * cq) = mx;
+}
+
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const float* __restrict__ x, const float* __restrict__ dy,
                                                             int C, int dps, const float* __restrict__ coef,
                                                             float* __restrict__ part) {
@@ -778,7 +807,12 @@ static unsigned bn_blocks(size_t npix, int C) {
 }
 
 // forward (training statistics, or inference with the moving statistics); returns false when the shape is not covered
-bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps) {
+bool fast_bn_pool_fusable(const Model* m, const Op& bn, const Op& pool) {
+    return fast_bn_supported(m, bn) && pool.type == OP_POOL && pool.k == 2 && pool.inA.d.p == bn.out.d.p && bn.out.d.ps == bn.out.d.C &&
+           pool.out.d.ps == pool.out.d.C && bn.out.d.H % 2 == 0 && bn.out.d.W % 2 == 0;
+}
+
+bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps, Op* pool) {
     if (!bn_fast_ok(o.inA.d) || o.out.d.ps % 4) return false;
     const int C = o.inA.d.C;
     const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
@@ -809,6 +843,12 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
                              m->state + o.mv_off, o.coef, 0, momentum, eps));
     }
     const size_t n4 = npix * (C / 4);
+    if (pool) {          // the caller checked fast_bn_pool_fusable(o, *pool)
+        LAUNCH(m, "bn_apply_pool", 2.25 * tb, tb / 2,
+               hipLaunchKernelGGL(k_bn_apply_pool_fast, dim3((unsigned)((n4 / 4 + 255) / 256)), dim3(256), 0, m->stream, n4 / 4,
+                                  o.inA.d.p, o.out.d.p, pool->out.d.p, C, o.inA.d.H, o.inA.d.W, o.coef));
+        return true;
+    }
     LAUNCH(m, "bn_apply", 2 * tb, tb / 2,
            hipLaunchKernelGGL(k_bn_apply_fast, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, m->stream, n4, o.inA.d.p,
                               o.out.d.p, C, o.out.d.ps, o.coef));

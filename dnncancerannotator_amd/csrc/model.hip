@@ -398,7 +398,11 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 int C = o.inA.d.C;
                 double n = (double)B * o.inA.d.H * o.inA.d.W;
                 double tb = 4.0 * nelem(B, o.inA.d);
-                if (!generic && fast_bn_fwd(this, B, o, training, kBnMomentum, kBnEps)) break;
+                Op* bn_pool = (!generic && oi + 1 < ops.size() && fast_bn_pool_fusable(this, o, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
+                if (!generic && fast_bn_fwd(this, B, o, training, kBnMomentum, kBnEps, bn_pool)) {
+                    if (bn_pool) pool_done = bn_pool;
+                    break;
+                }
                 if (training) {
                     if (!dry) HIP_TRY(hipMemsetAsync(o.ws, 0, (size_t)2 * C * 8, stream));
                     LAUNCH(this, "g_bn_stats_mean", tb, tb / 4, g_bn_stats_mean(stream, B, o.inA.d, o.ws));
