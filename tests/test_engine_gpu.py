@@ -371,3 +371,37 @@ def test_label_smoothing_loss_matches_oracle(gpu, force_generic):
     plain = m.train_step(x, y, 0.0, m.loss_cfg(weight_mul=3.0))
     assert abs(plain.loss - out.loss) > 1e-3                  # and it is not a no-op
     m.close()
+
+
+@pytest.mark.parametrize('arch,C,B,opts', [
+    ('mulmo', 3, 2, dict(n_filters_first=16, n_downsample=4, bn=True)),       # configs/mulmo_unet.yaml
+    ('unet', 1, 1, dict(n_filters_first=64, n_downsample=4, bn=True)),        # configs/unet_big.yaml (fp32 contraction)
+])
+def test_dense_configs_full_resolution_tuned_vs_generic(gpu, arch, C, B, opts):
+    """The dense-channel configurations at the BASELINE resolution (512 x 512): the second-generation kernels (persistent conv,
+    tiled weight gradients, fused BatchNorm statistics / pool, first-layer kernels, transposed-conv kernels) against the generic
+    kernels on the same weights -- logits of an inference pass, and loss / gradients / BatchNorm moving statistics of a training
+    step.  Tolerances: the networks are deep and freshly initialised (fp32 accumulation order differs between the paths)."""
+    from dnncancerannotator_amd.synthetic import synthetic_batch
+    H = W = 512
+    full = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', **opts)
+    x, y = synthetic_batch(B, H, W, C)
+    tuned = gpu.DeviceModel(arch, C, H, W, B, **full)
+    generic = gpu.DeviceModel(arch, C, H, W, B, force_generic=True, **full)
+    tuned.init_glorot(seed=3)
+    p0 = tuned.get_params()
+    generic.set_params(p0)
+    _, lt = tuned.forward(x, training=False, return_logits=True)
+    _, lg = generic.forward(x, training=False, return_logits=True)
+    assert np.abs(lt - lg).max() <= 1e-3 * max(1.0, float(np.abs(lg).max()))
+    cfg = tuned.loss_cfg(weight_mul=3.0)
+    ot = tuned.train_step(x, y, 0.0, cfg)
+    og = generic.train_step(x, y, 0.0, cfg)
+    assert abs(ot.loss - og.loss) <= 1e-4 * max(1.0, abs(og.loss))
+    gt, gg = tuned.get_grads().astype(np.float64), generic.get_grads().astype(np.float64)
+    assert np.linalg.norm(gt - gg) <= 2e-2 * np.linalg.norm(gg), np.linalg.norm(gt - gg) / np.linalg.norm(gg)
+    assert Hp.rel_err(tuned.get_state(), generic.get_state()) <= 1e-4          # BatchNorm moving statistics
+    names = set(r[0] for r in tuned.plan())
+    assert {'ig_conv_fwd', 'ig_wgrad2', 'first_fwd', 'bn_apply_pool'} <= names
+    tuned.close()
+    generic.close()
