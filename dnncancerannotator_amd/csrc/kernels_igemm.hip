@@ -1971,11 +1971,13 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
     a.tiles_x = (a.W + ig::TX - 1) / ig::TX;
     a.tiles_y = (a.H + ig::TY - 1) / ig::TY;
     a.alpha = o.alpha;
-    if (bn_next && !m->dry && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
+    if (bn_next && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
         // the BatchNorm behind this conv takes its batch statistics from the conv's epilogue
         const int rows = conv3_rows(a);
         void* part = nullptr;
-        if (bn_scratch(m, (size_t)rows * 2 * o.out.d.C * 4, &part)) {
+        if (m->dry) {
+            bn_next->fused_stats_rows = rows;          // the dry run lists the launches of the real one
+        } else if (bn_scratch(m, (size_t)rows * 2 * o.out.d.C * 4, &part)) {
             a.bn_part = (float*)part;
             bn_next->fused_stats_rows = rows;
         }

@@ -818,7 +818,7 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
     const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
     const double tb = 4.0 * npix * C;
     if (training) {
-        if (o.fused_stats_rows > 0 && !m->dry) {
+        if (o.fused_stats_rows > 0) {
             // the producing conv left [rows][2C] float partials in the partials table (its epilogue saw every output value)
             const int rows = o.fused_stats_rows;
             o.fused_stats_rows = 0;
