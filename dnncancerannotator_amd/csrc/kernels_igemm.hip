@@ -2010,10 +2010,10 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         const int combos = (cs / (16 * mw)) * (CO / (16 * nn));
         return (256 + combos - 1) / combos;
     };
-    if (!m->dry && wgrad2_path(CA) && (!CB || wgrad2_path(CB)) && n_w + CO <= WG_SLAB_FLOATS && wgrad2_psplit(CA) > 32 &&
+    if (wgrad2_path(CA) && (!CB || wgrad2_path(CB)) && n_w + CO <= WG_SLAB_FLOATS && wgrad2_psplit(CA) > 32 &&
         !getenv("DNNCA_NO_WG_BUCKETS")) {
-        if (!pl.wg_slabs && m->alloc((void**)&pl.wg_slabs, (size_t)WG_BUCKETS * WG_SLAB_FLOATS * 4) != DNNCA_OK) pl.wg_slabs = nullptr;
-        bucketed = pl.wg_slabs != nullptr;
+        if (!pl.wg_slabs && !m->dry && m->alloc((void**)&pl.wg_slabs, (size_t)WG_BUCKETS * WG_SLAB_FLOATS * 4) != DNNCA_OK) pl.wg_slabs = nullptr;
+        bucketed = m->dry || pl.wg_slabs != nullptr;          // the dry run lists the launches of the real one
     }
     // weight (+bias) gradient, one launch per source
     for (int s = 0; s < (CB ? 2 : 1); ++s) {
