@@ -638,9 +638,25 @@ void g_finalize_scalars(hipStream_t s, double* scalars, const dnnca_loss_cfg cfg
 }
 
 // ------------------------------------------------------------------------------------------------ Adam (Keras)
+// fin != nullptr: block 0 / thread 0 also turns the step's scalar block into the five step outputs (k_finalize_scalars' job;
+// single-replica steps only -- under data parallel the loss slot must be final before the all-reduce)
+struct AdamFinalize {
+    double* scalars;
+    dnnca_loss_cfg cfg;
+    double n_label, inv_batch_hw;
+    float* out5;
+};
+
 __global__ void k_adam(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                       float* __restrict__ v, float lr_t, float b1, float b2, float eps, float gscale) {
+                       float* __restrict__ v, float lr_t, float b1, float b2, float eps, float gscale, AdamFinalize fin) {
     size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    if (i == 0 && fin.out5) {
+        fin.out5[0] = (float)(fin.scalars[3] * fin.inv_batch_hw + fin.scalars[4]);
+        fin.out5[1] = (float)(fin.scalars[0] / fin.n_label);
+        fin.out5[2] = loss_weight(fin.cfg, fin.scalars[0], fin.n_label);
+        fin.out5[3] = (float)fin.scalars[1];
+        fin.out5[4] = (float)fin.scalars[2];
+    }
     if (i >= n) return;
     float gi = g[i] * gscale;
     float mi = m[i] * b1 + gi * (1.f - b1);
@@ -652,7 +668,13 @@ __global__ void k_adam(size_t n, float* __restrict__ p, const float* __restrict_
 
 void g_adam(hipStream_t s, size_t n, float* p, const float* g, float* m, float* v, float lr_t, float b1, float b2, float eps,
             float gscale) {
-    hipLaunchKernelGGL(k_adam, dim3(nblk(n)), dim3(TB), 0, s, n, p, g, m, v, lr_t, b1, b2, eps, gscale);
+    hipLaunchKernelGGL(k_adam, dim3(nblk(n)), dim3(TB), 0, s, n, p, g, m, v, lr_t, b1, b2, eps, gscale, AdamFinalize{});
+}
+
+void g_adam_finalize(hipStream_t s, size_t n, float* p, const float* g, float* m, float* v, float lr_t, float b1, float b2, float eps,
+                     float gscale, double* scalars, const dnnca_loss_cfg cfg, double n_label, double inv_batch_hw, float* out5) {
+    hipLaunchKernelGGL(k_adam, dim3(nblk(n)), dim3(TB), 0, s, n, p, g, m, v, lr_t, b1, b2, eps, gscale,
+                       AdamFinalize{scalars, cfg, n_label, inv_batch_hw, out5});
 }
 
 // ------------------------------------------------------------------------------------------------ pixel confusion

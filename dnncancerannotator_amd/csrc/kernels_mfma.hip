@@ -623,9 +623,38 @@ __device__ __forceinline__ int slab_index(int mrow, int n) {
 
 // dW[dy][kx][ci][co] = sum_slabs sum_dx D[(dy, (dx + kx)*C + ci), (dx, co)];  db[co] = sum_dx D[ones row, (dx, co)]
 // Every block first sums the NBUCKET slabs into LDS (coalesced, independent loads), then folds its 256 outputs.
+// Blocks with blockIdx.x >= nfolds (y == 0) reduce the fused head's per-block partials instead (k_head_reduce's job: value
+// k = blockIdx.x - nfolds of [dW (C), db, loss sum]), so that the backward pass ends in one launch.
+struct HeadTail {
+    const float* partials;
+    int nblocks, C;
+    float* dw;
+    float* dbias;
+    double* scalars;
+};
+
 __global__ __launch_bounds__(256) void k_pg_fold(const FoldDesc* __restrict__ descs, const float* __restrict__ slabs,
-                                                 float* __restrict__ grads) {
+                                                 float* __restrict__ grads, int nfolds, HeadTail h) {
     __shared__ float Dl[7 * 256];
+    if ((int)blockIdx.x >= nfolds) {
+        if (blockIdx.y != 0) return;
+        double* red = reinterpret_cast<double*>(Dl);
+        const int k = blockIdx.x - nfolds;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < h.nblocks; i += 256) s += (double)h.partials[i * (h.C + 2) + k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (k < h.C) h.dw[k] = (float)red[0];
+            else if (k == h.C) h.dbias[0] = (float)red[0];
+            else h.scalars[3] = red[0];
+        }
+        return;
+    }
     const FoldDesc d = descs[blockIdx.x];
     {
         const int total = d.kind == 1 ? 4 * d.CO * d.C + d.CO : 9 * d.C * d.CO + (d.b_off >= 0 ? d.CO : 0);
@@ -856,6 +885,7 @@ static int build_plan(Model* m, PgPlan& pl) {
         DN_TRY(m->alloc((void**)&pl.folds_dev, pl.folds.size() * sizeof(FoldDesc)));
         DN_TRY(m->alloc((void**)&pl.slabs, (slab_floats + 4) * 4));
         m->extra_zero = pl.slabs;           // accumulated with atomics: model.hip zeroes them at the top of each backward
+        m->head_defer_ok = true;            // k_pg_fold ends every backward pass: it also reduces the fused head's partials
         m->extra_zero_n = slab_floats;
         HIP_TRY(hipMemcpyAsync(pl.folds_dev, pl.folds.data(), pl.folds.size() * sizeof(FoldDesc), hipMemcpyHostToDevice, m->stream));
     }
@@ -1011,9 +1041,17 @@ int fast_finish_backward(Model* m) {
     if (m->desc.flags & 1) return DNNCA_OK;
     PgPlan& pl = g_plans[m];
     if (!pl.built || pl.folds.empty()) return DNNCA_OK;
+    HeadTail h{};
+    int extra = 0;
+    if (m->head_pending.partials) {
+        h.partials = m->head_pending.partials; h.nblocks = m->head_pending.nblocks; h.C = m->head_pending.C;
+        h.dw = m->head_pending.dw; h.dbias = m->head_pending.dbias; h.scalars = m->scalars;
+        extra = h.C + 2;
+        m->head_pending.partials = nullptr;
+    }
     LAUNCH(m, "pg_fold", 0, 0,
-           hipLaunchKernelGGL(k_pg_fold, dim3((unsigned)pl.folds.size(), pl.fold_chunks), dim3(256), 0, m->stream,
-                              pl.folds_dev, pl.slabs, m->g));
+           hipLaunchKernelGGL(k_pg_fold, dim3((unsigned)pl.folds.size() + extra, pl.fold_chunks), dim3(256), 0, m->stream,
+                              pl.folds_dev, pl.slabs, m->g, (int)pl.folds.size(), h));
     return DNNCA_OK;
 }
 

@@ -68,6 +68,11 @@ struct Model {
     float* out5 = nullptr;               // = g + nT : [loss, positive_rate, weight, ymin, ymax]
     float *x_stage = nullptr, *y_stage = nullptr, *logits = nullptr, *dlogits = nullptr, *prob = nullptr;
     float* thr_dev = nullptr;
+    // the fused head's partial sums wait for the launch that ends the backward pass (k_pg_fold reduces them: one launch less)
+    struct HeadPending { const float* partials = nullptr; int nblocks = 0, C = 0; float* dw = nullptr; float* dbias = nullptr; } head_pending;
+    bool head_defer_ok = false;
+    // single-replica training steps: the step outputs are written by the Adam launch instead of a launch of their own
+    struct FinalizePending { bool on = false; dnnca_loss_cfg cfg; double n_label = 0, inv_batch_hw = 0; } fin_pending;          // set by the pixel-group plan when a k_pg_fold launch exists
     float* y_smooth = nullptr;           // smoothed labels of the step (label_smoothing, utils/losses.py:62-67)
     void* warp_scratch = nullptr;        // control points + spline weights of dnnca_warp_f32
     size_t warp_scratch_bytes = 0;

@@ -448,6 +448,8 @@ int Model::forward(const float* x_dev, int B, bool training) {
 // ---------------------------------------------------------------------------------------------- loss + backward
 int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cfg, bool backward) {
     cur_op = nullptr;
+    head_pending.partials = nullptr;    // leftovers of a step that stopped on an error
+    fin_pending.on = false;
     if (cfg.label_smoothing) {          // utils/losses.py:62-67: every later use of y_true (positive rate, assertions, loss) sees the blurred labels
         if (!y_smooth) DN_TRY(alloc((void**)&y_smooth, (size_t)desc.max_batch * outH * outW * 4));
         if (!fast_label_smooth(this, B, outH, outW, y_dev, y_smooth, cfg.label_smoothing_filter_size, cfg.label_smoothing_sigma)) {
@@ -563,6 +565,14 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                    g_l2(stream, (size_t)pi.size, p + pi.offset, g + pi.offset, desc.l2, scalars));
         }
     }
+    if (backward && !comm && !dry && prof_mode == 0) {
+        // optimizer_step() follows every backward pass: its Adam launch also writes the step outputs (one launch fewer)
+        fin_pending.on = true;
+        fin_pending.cfg = cfg;
+        fin_pending.n_label = (double)npix;
+        fin_pending.inv_batch_hw = 1.0 / ((double)outH * outW * B);
+        return DNNCA_OK;
+    }
     LAUNCH(this, "g_finalize_scalars", 0, 0,
            g_finalize_scalars(stream, scalars, cfg, (double)npix, 1.0 / ((double)outH * outW * B), out5));
     return DNNCA_OK;
@@ -580,6 +590,13 @@ int Model::optimizer_step(float lr) {
     iterations += dry ? 0 : 1;
     double t = (double)(dry ? 1 : iterations);
     float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+    if (fin_pending.on) {
+        fin_pending.on = false;
+        LAUNCH(this, "g_adam", 28.0 * nT, 10.0 * nT,
+               g_adam_finalize(stream, (size_t)nT, p, g, m, v, lr_t, beta1, beta2, eps, gscale, scalars, fin_pending.cfg,
+                               fin_pending.n_label, fin_pending.inv_batch_hw, out5));
+        return DNNCA_OK;
+    }
     LAUNCH(this, "g_adam", 28.0 * nT, 10.0 * nT, g_adam(stream, (size_t)nT, p, g, m, v, lr_t, beta1, beta2, eps, gscale));
     return DNNCA_OK;
 }
