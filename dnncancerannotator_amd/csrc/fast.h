@@ -20,7 +20,6 @@ bool fast_pool_fwd(Model* m, int B, Op& o, double bytes);
 bool fast_pool_bwd(Model* m, int B, Op& o, double bytes);
 bool fast_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops);
 bool fast_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
-bool fast_tconv_dgrad(Model* m, int B, Op& o, double bytes, double flops);
 bool fast_pool_supported(const Model* m, const Op& o);
 bool fast_tconv_supported(const Model* m, const Op& o);
 bool fast_head_supported(const Model* m, const Op& o);

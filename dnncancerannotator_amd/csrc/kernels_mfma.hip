@@ -24,6 +24,7 @@
 
 #include "fast.h"
 #include "kernels.h"
+#include "tconv2_dev.h"
 
 namespace dnnca {
 
@@ -598,9 +599,25 @@ __global__ void k_pg_prep_index(const PrepDesc* __restrict__ descs, int* __restr
     }
 }
 
-// every step: B operands <- current weights (a plain gather)
+// every step: B operands <- current weights (a plain gather).  On a train step the blocks past `nprep` do k_step_init's job
+// (scalar block, flat gradient vector, weight-gradient slabs) so that the loss does not need a launch for it.
+struct StepInit {
+    double* scalars;
+    float4* a;
+    float4* b;
+    unsigned na4, nb4;
+};
+
 __global__ __launch_bounds__(256) void k_pg_prep(const int* __restrict__ index, const float* __restrict__ params,
-                                                 float* __restrict__ bmat, int n) {
+                                                 float* __restrict__ bmat, int n, int nprep, StepInit z) {
+    if ((int)blockIdx.x >= nprep) {
+        const unsigned T = (gridDim.x - nprep) * 256u, i0 = (blockIdx.x - nprep) * 256u + threadIdx.x;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (unsigned i = i0; i < z.na4; i += T) z.a[i] = zero;
+        for (unsigned i = i0; i < z.nb4; i += T) z.b[i] = zero;
+        if (i0 < 8) z.scalars[i0] = i0 == 1 ? (double)INFINITY : (i0 == 2 ? -(double)INFINITY : 0.0);   // see k_step_init
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int j = index[i];
@@ -717,7 +734,7 @@ struct TwArgs {
 };
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_tconv_wgrad(TwArgs p) {
+__device__ __forceinline__ void tconv_wgrad_body(const TwArgs& p, const int bid, const int nblocks) {
     constexpr int MROWS = 4 * COUT, MT = (MROWS + 15) / 16;
     __shared__ float red[4 * MT * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -734,7 +751,7 @@ __global__ __launch_bounds__(256) void k_tconv_wgrad(TwArgs p) {
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int gw = bid * 4 + wave, nw = nblocks * 4;
     constexpr int UQ = 4;          // quads per iteration: all their loads are in flight before the first MFMA
     for (int quad0 = gw * UQ; quad0 < p.nquads; quad0 += nw * UQ) {
         float av[UQ][MT], bv[UQ];
@@ -759,9 +776,17 @@ __global__ __launch_bounds__(256) void k_tconv_wgrad(TwArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[(wave * MT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
     __syncthreads();
-    float* slab = p.slabs + (size_t)(blockIdx.x % NBUCKET) * (MT * 256);
+    float* slab = p.slabs + (size_t)(bid % NBUCKET) * (MT * 256);
     for (int i = tid; i < MT * 256; i += 256)
         atomicAdd(slab + i, (red[i] + red[MT * 256 + i]) + (red[2 * MT * 256 + i] + red[3 * MT * 256 + i]));
+}
+
+// the whole backward of a small transposed conv in one launch: blocks [0, nbw) accumulate the weight gradient, the rest
+// compute the data gradient (both only read dout; a launch of its own costs each of them more than its work at 64^2..256^2)
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_tconv_bwd(TwArgs w, TdArgs d, int nbw) {
+    if ((int)blockIdx.x < nbw) tconv_wgrad_body<CIN, COUT>(w, blockIdx.x, nbw);
+    else tconv2_dgrad_body<CIN, COUT>(d, ((int)blockIdx.x - nbw) * 256 + threadIdx.x);
 }
 
 // ================================================================================================ host side
@@ -907,9 +932,21 @@ int fast_prepare(Model* m) {
     PgPlan& pl = g_plans[m];
     if (!pl.built) DN_TRY(build_plan(m, pl));
     if (pl.descs.empty()) return DNNCA_OK;
+    const int nprep = (pl.bmat_n + 255) / 256;
+    StepInit z{};
+    int nz = 0;
+    if (m->defer_head && m->prof_mode == 0 && !m->dry) {      // dnnca_train_step: a backward pass follows this forward pass
+        z.scalars = m->scalars;
+        z.a = reinterpret_cast<float4*>(m->g);
+        z.na4 = (unsigned)((m->nT + 8 + 3) / 4);                // both buffers are allocated with >= 16 bytes of slack
+        z.b = reinterpret_cast<float4*>(m->extra_zero);
+        z.nb4 = (unsigned)((m->extra_zero_n + 3) / 4);
+        nz = (int)((z.na4 + z.nb4 + 1023) / 1024);
+        nz = nz < 1 ? 1 : (nz > 1024 ? 1024 : nz);
+        m->step_init_done = true;
+    }
     LAUNCH(m, "pg_prep", 0, 0,
-           hipLaunchKernelGGL(k_pg_prep, dim3((pl.bmat_n + 255) / 256), dim3(256), 0, m->stream, pl.bindex, m->p, pl.bmat,
-                              pl.bmat_n));
+           hipLaunchKernelGGL(k_pg_prep, dim3(nprep + nz), dim3(256), 0, m->stream, pl.bindex, m->p, pl.bmat, pl.bmat_n, nprep, z));
     return DNNCA_OK;
 }
 
@@ -1023,17 +1060,18 @@ bool fast_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, d
     int nb = a.nquads / 64;
     nb = nb < 64 ? 64 : (nb > 1024 ? 1024 : nb);
     const int CI = o.inA.d.C, CO = o.out.d.C;
-    bool done = false;
+    const int H = o.inA.d.H, W = o.inA.d.W;
+    const TdArgs d{o.out.g.p, m->p + o.w_off, o.inA.d.p, o.inA.g.p, B, H, W, (int)o.accA, (int)o.maskA, o.mask_alpha};
+    const int nbd = (B * H * W + 255) / 256;
 #define TW_CASE(ci, co)                                                                                       \
     if (CI == ci && CO == co) {                                                                               \
-        LAUNCH(m, "tconv_wgrad_" #ci "_" #co, out_bytes + in_bytes, flops,                                    \
-               hipLaunchKernelGGL((k_tconv_wgrad<ci, co>), dim3(nb), dim3(256), 0, m->stream, a));            \
-        done = true;                                                                                          \
+        LAUNCH(m, "tconv_bwd_" #ci "_" #co, 2 * (out_bytes + in_bytes), 2 * flops,                            \
+               hipLaunchKernelGGL((k_tconv_bwd<ci, co>), dim3(nb + nbd), dim3(256), 0, m->stream, a, d, nb)); \
+        return true;                                                                                          \
     }
     TW_CASE(12, 12) TW_CASE(12, 6) TW_CASE(6, 3)
 #undef TW_CASE
-    if (!done) return false;
-    return fast_tconv_dgrad(m, B, o, out_bytes + in_bytes, flops);
+    return false;
 }
 
 // after the last backward op: fold every slab set into the flat gradient vector (one launch)

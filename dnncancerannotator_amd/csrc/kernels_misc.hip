@@ -184,58 +184,6 @@ __global__ __launch_bounds__(256) void k_tconv2_fwd(const float* __restrict__ in
     }
 }
 
-// data gradient: one thread = one input pixel; din = ((acc ? din : 0) + sum dout * W) * (mask ? act'(in) : 1)
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_tconv2_dgrad(const float* __restrict__ dout, const float* __restrict__ w,
-                                                      const float* __restrict__ in, float* __restrict__ din, int B, int H,
-                                                      int W, int acc, int mask, float alpha) {
-    const int total = B * H * W;
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= total) return;
-    const int j = id % W, bi = id / W;
-    float d[CIN];
-#pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) d[ci] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        float g[2 * COUT];
-        const float* gp = dout + (((size_t)bi * 2 + a) * (2 * W) + 2 * j) * COUT;
-        if constexpr ((2 * COUT) % 4 == 0) {
-#pragma unroll
-            for (int v = 0; v < 2 * COUT / 4; ++v) ld4(g + 4 * v, gp + 4 * v);
-        } else {
-#pragma unroll
-            for (int v = 0; v < COUT; ++v) {
-                float2 t = *reinterpret_cast<const float2*>(gp + 2 * v);
-                g[2 * v] = t.x;
-                g[2 * v + 1] = t.y;
-            }
-        }
-        const float* wa = w + a * 2 * COUT * CIN;
-#pragma unroll
-        for (int r = 0; r < 2 * COUT; ++r)
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) d[ci] = fmaf(g[r], wa[r * CIN + ci], d[ci]);
-    }
-    float* dp = din + (size_t)id * CIN;
-    if (acc) {
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) d[ci] += dp[ci];
-    }
-    if (mask) {
-        const float* ip = in + (size_t)id * CIN;
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) d[ci] *= ip[ci] > 0.f ? 1.0f : alpha;
-    }
-    if constexpr (CIN % 4 == 0) {
-#pragma unroll
-        for (int v = 0; v < CIN / 4; ++v) st4(dp + 4 * v, d + 4 * v);
-    } else {
-#pragma unroll
-        for (int v = 0; v < CIN / 2; ++v) *reinterpret_cast<float2*>(dp + 2 * v) = make_float2(d[2 * v], d[2 * v + 1]);
-    }
-}
-
 bool fast_tconv_supported(const Model* m, const Op& o) {
     if (o.type != OP_TCONV || o.k != 2) return false;
     if (!dense(o.inA.d) || !dense(o.out.d)) return false;
@@ -255,21 +203,6 @@ bool fast_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
         LAUNCH(m, "tconv2_fwd_" #ci "_" #co, bytes, flops,                                                      \
                hipLaunchKernelGGL((k_tconv2_fwd<ci, co>), grid, dim3(256), 0, m->stream, o.inA.d.p, m->p + o.w_off, \
                                   m->p + o.b_off, o.out.d.p, B, H, W));                                         \
-        return true;                                                                                            \
-    }
-    TCONV_CASES(X)
-#undef X
-    return false;
-}
-
-bool fast_tconv_dgrad(Model* m, int B, Op& o, double bytes, double flops) {
-    const int CI = o.inA.d.C, CO = o.out.d.C, H = o.inA.d.H, W = o.inA.d.W;
-    dim3 grid((B * H * W + 255) / 256);
-#define X(ci, co)                                                                                               \
-    if (CI == ci && CO == co) {                                                                                 \
-        LAUNCH(m, "tconv2_dgrad_" #ci "_" #co, bytes, flops,                                                    \
-               hipLaunchKernelGGL((k_tconv2_dgrad<ci, co>), grid, dim3(256), 0, m->stream, o.out.g.p, m->p + o.w_off, \
-                                  o.inA.d.p, o.inA.g.p, B, H, W, (int)o.accA, (int)o.maskA, o.mask_alpha));     \
         return true;                                                                                            \
     }
     TCONV_CASES(X)

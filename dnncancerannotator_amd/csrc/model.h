@@ -71,6 +71,7 @@ struct Model {
     // the fused head's partial sums wait for the launch that ends the backward pass (k_pg_fold reduces them: one launch less)
     struct HeadPending { const float* partials = nullptr; int nblocks = 0, C = 0; float* dw = nullptr; float* dbias = nullptr; } head_pending;
     bool head_defer_ok = false;
+    bool step_init_done = false;      // train step: the launch that prepares the pixel-group B operands already zeroed scalars / gradients / slabs
     // single-replica training steps: the step outputs are written by the Adam launch instead of a launch of their own
     struct FinalizePending { bool on = false; dnnca_loss_cfg cfg; double n_label = 0, inv_batch_hw = 0; } fin_pending;          // set by the pixel-group plan when a k_pg_fold launch exists
     float* y_smooth = nullptr;           // smoothed labels of the step (label_smoothing, utils/losses.py:62-67)

@@ -370,6 +370,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
             o.inA.d.p = const_cast<float*>(x_dev) + off;
         }
     xin.d.p = const_cast<float*>(x_dev);
+    step_init_done = false;
     DN_TRY(fast_prepare(this));
     DN_TRY(ig_prepare(this));
 
@@ -462,9 +463,11 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
     const bool generic = desc.flags & 1;
     size_t npix = (size_t)B * outH * outW;
     // scalars: label sum 0, min +inf, max -inf, loss 0, l2 0
-    LAUNCH(this, "g_step_init", 0, 0,
-           g_step_init(stream, scalars, g, backward ? (size_t)(nT + 8) : 0, extra_zero,
-                       backward && !generic ? extra_zero_n : 0));
+    if (!(step_init_done && backward))
+        LAUNCH(this, "g_step_init", 0, 0,
+               g_step_init(stream, scalars, g, backward ? (size_t)(nT + 8) : 0, extra_zero,
+                           backward && !generic ? extra_zero_n : 0));
+    step_init_done = false;
     if (generic || !fast_label_stats(this, npix, y_dev))
         LAUNCH(this, "g_label_stats", 4.0 * npix, (double)npix, g_label_stats(stream, npix, y_dev, scalars));
     // dlogits scale: mean over (H, W), then mean over the (rank-local) batch.  Under data parallel every rank uses its

@@ -26,7 +26,7 @@ def short_name(k):
     m = re.match(r'dnnca::k_(pool2_bwd|pool2_fwd|head_train|head_reduce)<(\d+)', k)
     if m:
         return '%s_%s' % m.groups()
-    m = re.match(r'dnnca::k_(tconv2_fwd|tconv2_dgrad|tconv_wgrad)<(\d+), (\d+)', k)
+    m = re.match(r'dnnca::k_(tconv2_fwd|tconv_bwd)<(\d+), (\d+)', k)
     if m:
         return '%s_%s_%s' % m.groups()
     m = re.match(r'dnnca::(?:ig::|igb::|first::)?k_(\w+)', k)
