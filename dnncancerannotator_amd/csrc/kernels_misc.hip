@@ -100,6 +100,9 @@ __global__ __launch_bounds__(256) void k_pool2_bwd(const float* __restrict__ in,
     }
 }
 
+__global__ void k_pool2_bwd_idx(size_t nwin4, const float* __restrict__ dout, const unsigned* __restrict__ idx,
+                                float* __restrict__ din, int C, int H, int W, int acc);        // with the BN kernels below
+
 bool fast_pool_supported(const Model* m, const Op& o) {
     if (o.type != OP_POOL || o.k != 2) return false;
     if (!dense(o.inA.d) || !dense(o.out.d)) return false;
@@ -125,6 +128,16 @@ bool fast_pool_fwd(Model* m, int B, Op& o, double bytes) {
 }
 
 bool fast_pool_bwd(Model* m, int B, Op& o, double bytes) {
+    if (o.pool_idx_valid && (o.pool_idx || m->dry) && dense(o.inA.g) && dense(o.out.g) && !o.maskA) {
+        // the fused BN-apply + pool pass of this step recorded where every maximum sits
+        o.pool_idx_valid = false;
+        const int C = o.out.d.C;
+        const size_t nwin4 = (size_t)B * o.out.d.H * o.out.d.W * (C / 4);
+        LAUNCH(m, "pool2_bwd_idx", (double)nwin4 * (16 + 4 + (o.accA ? 128 : 64)), 0,
+               hipLaunchKernelGGL(k_pool2_bwd_idx, dim3((unsigned)((nwin4 + 255) / 256)), dim3(256), 0, m->stream, nwin4, o.out.g.p,
+                                  reinterpret_cast<const unsigned*>(o.pool_idx), o.inA.g.p, C, o.inA.d.H, o.inA.d.W, (int)o.accA));
+        return true;
+    }
     if (!fast_pool_supported(m, o)) return false;
     const int C = o.out.d.C, Ho = o.out.d.H, Wo = o.out.d.W;
     const int total = B * Ho * (Wo * C / 12);
@@ -624,8 +637,8 @@ __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* _
 // BatchNorm apply + the MaxPool2D([2,2], 2) that follows it (components.py:54,59): one thread owns a 4-channel group of a 2 x 2
 // pixel window, writes the four normalised pixels and their maximum -- the pool pass never re-reads the normalised tensor.
 __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const float* __restrict__ x, float* __restrict__ y,
-                                                            float* __restrict__ pooled, int C, int H, int W,
-                                                            const float* __restrict__ coef) {
+                                                            float* __restrict__ pooled, unsigned* __restrict__ idx, int C, int H,
+                                                            int W, const float* __restrict__ coef) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nwin4) return;
     const int G = C / 4, cq = (int)(i % G), Wp = W / 2, Hp = H / 2;
@@ -637,6 +650,7 @@ __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const 
     const float4 sc = *reinterpret_cast<const float4*>(coef + 4 * cq), sh = *reinterpret_cast<const float4*>(coef + C + 4 * cq);
     const size_t p00 = ((b * H + 2 * yp) * W + 2 * xp) * C + 4 * cq;
     float4 mx;
+    unsigned where = 0;          // byte e: window position of channel e's first maximum (the order g_pool_bwd searches in)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const size_t o = p00 + ((size_t)(k >> 1) * W + (k & 1)) * C;
@@ -645,9 +659,40 @@ __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const 
         r.x = fmaf(v.x, sc.x, sh.x); r.y = fmaf(v.y, sc.y, sh.y); r.z = fmaf(v.z, sc.z, sh.z); r.w = fmaf(v.w, sc.w, sh.w);
         *reinterpret_cast<float4*>(y + o) = r;
         if (k == 0) mx = r;
-        else { mx.x = fmaxf(mx.x, r.x); mx.y = fmaxf(mx.y, r.y); mx.z = fmaxf(mx.z, r.z); mx.w = fmaxf(mx.w, r.w); }
+        else {
+            if (r.x > mx.x) { mx.x = r.x; where = (where & 0xffffff00u) | (unsigned)k; }
+            if (r.y > mx.y) { mx.y = r.y; where = (where & 0xffff00ffu) | ((unsigned)k << 8); }
+            if (r.z > mx.z) { mx.z = r.z; where = (where & 0xff00ffffu) | ((unsigned)k << 16); }
+            if (r.w > mx.w) { mx.w = r.w; where = (where & 0x00ffffffu) | ((unsigned)k << 24); }
+        }
     }
     *reinterpret_cast<float4*>(pooled + wdx * C + 4 * cq) = mx;
+    if (idx) idx[i] = where;
+}
+
+// MaxPool2D([2,2], 2) backward by the recorded positions: din = (acc ? din : 0) + route(dout); one thread = a 4-channel group of a window
+__global__ __launch_bounds__(256) void k_pool2_bwd_idx(size_t nwin4, const float* __restrict__ dout, const unsigned* __restrict__ idx,
+                                                       float* __restrict__ din, int C, int H, int W, int acc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nwin4) return;
+    const int G = C / 4, cq = (int)(i % G), Wp = W / 2, Hp = H / 2;
+    const size_t wdx = i / G;
+    const int xp = (int)(wdx % Wp);
+    const size_t byp = wdx / Wp, b = byp / Hp;
+    const int yp = (int)(byp - b * Hp);
+    const float4 g = reinterpret_cast<const float4*>(dout)[i];
+    const unsigned where = idx[i];
+    const size_t p00 = ((b * H + 2 * yp) * W + 2 * xp) * C + 4 * cq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4* o = reinterpret_cast<float4*>(din + p00 + ((size_t)(k >> 1) * W + (k & 1)) * C);
+        float4 r = acc ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((where & 0xffu) == (unsigned)k) r.x += g.x;
+        if (((where >> 8) & 0xffu) == (unsigned)k) r.y += g.y;
+        if (((where >> 16) & 0xffu) == (unsigned)k) r.z += g.z;
+        if ((where >> 24) == (unsigned)k) r.w += g.w;
+        *o = r;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const float* __restrict__ x, const float* __restrict__ dy,
@@ -782,9 +827,15 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
     }
     const size_t n4 = npix * (C / 4);
     if (pool) {          // the caller checked fast_bn_pool_fusable(o, *pool)
+        if (!pool->pool_idx && !m->dry) {
+            void* ix = nullptr;
+            if (m->alloc(&ix, (size_t)m->desc.max_batch * pool->out.d.H * pool->out.d.W * C) == DNNCA_OK) pool->pool_idx = (unsigned char*)ix;
+        }
+        pool->pool_idx_valid = m->dry || pool->pool_idx != nullptr;     // the dry run lists the launches of the real one
         LAUNCH(m, "bn_apply_pool", 2.25 * tb, tb / 2,
                hipLaunchKernelGGL(k_bn_apply_pool_fast, dim3((unsigned)((n4 / 4 + 255) / 256)), dim3(256), 0, m->stream, n4 / 4,
-                                  o.inA.d.p, o.out.d.p, pool->out.d.p, C, o.inA.d.H, o.inA.d.W, o.coef));
+                                  o.inA.d.p, o.out.d.p, pool->out.d.p, reinterpret_cast<unsigned*>(pool->pool_idx), C, o.inA.d.H,
+                                  o.inA.d.W, o.coef));
         return true;
     }
     LAUNCH(m, "bn_apply", 2 * tb, tb / 2,

@@ -38,6 +38,10 @@ struct Op {
     // BN batch statistics that rode in the producing conv's epilogue this step: rows of float partials waiting in the
     // model's partials table (0: none)
     int fused_stats_rows = 0;
+    // pool: position (0..3, row-major in the 2x2 window) of each output's first maximum, written by the fused BN-apply + pool
+    // pass of this step; the backward pass routes by it instead of re-reading the input and output tensors
+    unsigned char* pool_idx = nullptr;
+    bool pool_idx_valid = false;
 };
 
 struct ParamInfo {
@@ -70,10 +74,10 @@ struct Model {
     float* thr_dev = nullptr;
     // the fused head's partial sums wait for the launch that ends the backward pass (k_pg_fold reduces them: one launch less)
     struct HeadPending { const float* partials = nullptr; int nblocks = 0, C = 0; float* dw = nullptr; float* dbias = nullptr; } head_pending;
-    bool head_defer_ok = false;
+    bool head_defer_ok = false;           // set by the pixel-group plan when a k_pg_fold launch exists
     bool step_init_done = false;      // train step: the launch that prepares the pixel-group B operands already zeroed scalars / gradients / slabs
     // single-replica training steps: the step outputs are written by the Adam launch instead of a launch of their own
-    struct FinalizePending { bool on = false; dnnca_loss_cfg cfg; double n_label = 0, inv_batch_hw = 0; } fin_pending;          // set by the pixel-group plan when a k_pg_fold launch exists
+    struct FinalizePending { bool on = false; dnnca_loss_cfg cfg; double n_label = 0, inv_batch_hw = 0; } fin_pending;
     float* y_smooth = nullptr;           // smoothed labels of the step (label_smoothing, utils/losses.py:62-67)
     void* warp_scratch = nullptr;        // control points + spline weights of dnnca_warp_f32
     size_t warp_scratch_bytes = 0;
