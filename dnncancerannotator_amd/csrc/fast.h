@@ -35,6 +35,7 @@ void fast_plan_masks(Model* m);
 // implicit-GEMM MFMA path for channel counts that are multiples of 16 (kernels_igemm.hip)
 bool ig_conv_supported(const Model* m, const Op& o);
 int ig_prepare(Model* m);
+int ig_plan_half(Model* m);        // dtype bf16: decides View::h for every tensor (static per model; after fast_plan_masks)
 int ig_begin_backward(Model* m);
 void ig_release(Model* m);
 bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);   // bn_next: BatchNorm of the output whose statistics may ride in the epilogue

@@ -8,6 +8,8 @@
 // 288 (NN = 4) MFMAs per wave between two barriers; the decoder concat is two sources, never materialised; bias +
 // activation (forward) or act' mask + accumulate + destination split (data gradient) are fused into the store.
 // The data gradient is the forward kernel on a transposed + flipped copy of the weights (k_ig_flip, once per step).
+#include <type_traits>
+
 #include "fast.h"
 #include "kernels.h"
 
@@ -70,6 +72,7 @@ struct ConvArgs {
     float alpha;             // forward: activation slope (<0 none); data gradient: slope of the masked activation
     // forward: batch statistics of the BatchNorm behind this conv ride in the epilogue of the persistent kernels:
     float* bn_part;          // [tile][2 * Cout] float partials (sum, sum of squares per channel); nullptr: none
+    int src_half;            // the sources are stored as bf16 (View::h; k_igb_conv3 only)
 };
 
 // MODE 0 forward, MODE 1 data gradient
@@ -1237,7 +1240,8 @@ constexpr int OSTR = 68;                            // floats per pixel row of t
 constexpr unsigned BUF_FLAGS = 0x00020000u;         // raw buffer descriptor word 3 (gfx9 family)
 constexpr unsigned OOB = 0x80000000u;               // beyond every tensor here: the buffer load returns zeros
 
-template <int MODE>
+// A16: the sources are stored as bf16 (View::h): 16-byte loads of 8 channels go to LDS as they are
+template <int MODE, bool A16>
 __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* __restrict__ w16) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * BUF3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1251,7 +1255,8 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     if (nitems <= 0) return;
 
     const size_t npix = (size_t)p.B * p.H * p.W;
-    const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * 4), nbytes1 = (unsigned)(npix * p.c_src1 * 4);
+    constexpr unsigned ESZ = A16 ? 2 : 4;
+    const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * ESZ), nbytes1 = (unsigned)(npix * p.c_src1 * ESZ);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)w16, 0, (unsigned)((size_t)9 * nout * kin * 2), BUF_FLAGS);
 
     struct Unit { int b, y0, x0, co0, tile; };
@@ -1273,19 +1278,21 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         return u;
     };
 
-    // ---- staging geometry of this thread: A element v = patch pixel (tid >> 3) + 32 v, channels 4 (tid & 7)..;
+    // ---- staging geometry of this thread: A element v = patch pixel tid / TPP + PPV v, channels CPT (tid % TPP)..
+    //      (f32 sources: 8 threads x 4 channels per pixel; bf16 sources: 4 threads x 8 channels);
     //      B element v = tap v, output channel tid >> 2, K part tid & 3
-    constexpr int AU = (PATCH2 * 8 + 255) / 256, BU = 9;
-    const int c4 = tid & 7, bn = tid >> 2, bpart = tid & 3;
+    constexpr int TPP = A16 ? 4 : 8, PPV = 256 / TPP, CPT = CK / TPP;
+    constexpr int AU = (PATCH2 * TPP + 255) / 256, BU = 9;
+    const int c4 = tid & (TPP - 1), bn = tid >> 2, bpart = tid & 3;
     int a_ly[AU], a_lx[AU];
 #pragma unroll
     for (int v = 0; v < AU; ++v) {
-        const int px = (tid >> 3) + 32 * v;
+        const int px = tid / TPP + PPV * v;
         a_ly[v] = px / (T2 + 2);
         a_lx[v] = px - a_ly[v] * (T2 + 2);
         if (px >= PATCH2) a_ly[v] = -4096;          // never inside an image
     }
-    f32x4 ar[AU];
+    u32x4 ar[AU];
     u32x4 br[BU];
     // item being staged (uniform per block)
     struct Stage { int b, y0, x0, co0, cc, cs, c0; unsigned oob; __amdgpu_buffer_rsrc_t rs; };
@@ -1308,20 +1315,25 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     auto issue_a = [&](const Stage& st, int v) {
         const int iy = st.y0 - 1 + a_ly[v], ix = st.x0 - 1 + a_lx[v];
         const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const unsigned off = (ok ? (unsigned)(((((st.b * p.H + iy) * p.W + ix) * st.cs) + st.c0 + 4 * c4) * 4) : OOB) | st.oob;
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
-        ar[v] = __builtin_bit_cast(f32x4, t);
+        const unsigned off = (ok ? (unsigned)(((((st.b * p.H + iy) * p.W + ix) * st.cs) + st.c0 + CPT * c4) * ESZ) : OOB) | st.oob;
+        ar[v] = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
     };
     auto issue_b = [&](const Stage& st, int v) {
         const unsigned off = (unsigned)((((v * nout + st.co0 + bn) * kin) + st.cc + 8 * bpart) * 2) | st.oob;
         br[v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0);
     };
     auto commit_a = [&](bf16_t* buf, int v) {
-        const int px = (tid >> 3) + 32 * v;
-        bf16x4 h;
-        h[0] = (bf16_t)ar[v][0]; h[1] = (bf16_t)ar[v][1]; h[2] = (bf16_t)ar[v][2]; h[3] = (bf16_t)ar[v][3];
+        const int px = tid / TPP + PPV * v;
         // branch-free: lanes past the patch (last element only) write into the buffer's dump row
-        *reinterpret_cast<bf16x4*>(buf + (px < PATCH2 ? px * RS : (PATCH2 + 9 * 64) * RS) + 4 * c4) = h;
+        bf16_t* dst = buf + (px < PATCH2 ? px * RS : (PATCH2 + 9 * 64) * RS) + CPT * c4;
+        if constexpr (A16) {
+            *reinterpret_cast<u32x4*>(dst) = ar[v];
+        } else {
+            const f32x4 f = __builtin_bit_cast(f32x4, ar[v]);
+            bf16x4 h;
+            h[0] = (bf16_t)f[0]; h[1] = (bf16_t)f[1]; h[2] = (bf16_t)f[2]; h[3] = (bf16_t)f[3];
+            *reinterpret_cast<bf16x4*>(dst) = h;
+        }
     };
     auto commit_b = [&](bf16_t* buf, int v) {
         *reinterpret_cast<u32x4*>(buf + PATCH2 * RS + (64 * v + bn) * RS + 8 * bpart) = br[v];
@@ -1383,8 +1395,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
                 const int v0 = s - 1, v1 = s + 7;
                 // unconditional (straight-line code the scheduler can weave between the MFMAs): past the last item the
                 // commit writes stale registers into the buffer nobody reads again and the loads are out of range
-                commit_a(other, v0);
-                issue_a(nx, v0);
+                if (v0 < AU) { commit_a(other, v0); issue_a(nx, v0); }
                 if (v1 < AU) { commit_a(other, v1); issue_a(nx, v1); }
                 commit_b(other, v0);
                 issue_b(nx, v0);
@@ -1468,6 +1479,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row0, const bf16_t* row1
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// X16 / G16: x / dz are stored as bf16 (View::h) and go to LDS as they are
+template <bool X16, bool G16>
 __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
     __shared__ __attribute__((aligned(16))) bf16_t ximg[PATCH * WRS];
     __shared__ __attribute__((aligned(16))) bf16_t gimg[TY * TX * WRS];
@@ -1490,7 +1503,12 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
     for (int j = 0; j < 4; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int XU = (PATCH * 16 + 255) / 256, GU = TY * TX * 16 / 256;      // 12 and 8 float4 per thread
-    float4 xr[XU], gr[GU];
+    using XR = std::conditional_t<X16, bf16x4, float4>;
+    using GR = std::conditional_t<G16, bf16x4, float4>;
+    XR xr[XU];
+    GR gr[GU];
+    const bf16_t* x16 = reinterpret_cast<const bf16_t*>(p.x);
+    const bf16_t* g16 = reinterpret_cast<const bf16_t*>(p.dz);
     auto issue = [&](int tile) {
         const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
         const int x0 = bx * TX, y0 = by * TY;
@@ -1499,18 +1517,30 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
             const int i = tid + 256 * u, px = i >> 4, c4 = i & 15;
             const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
             const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
-            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (px < PATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                xr[u] = *reinterpret_cast<const float4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.cs + c0 + 4 * c4);
+            const bool ok = px < PATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const size_t o = (((size_t)b * p.H + iy) * p.W + ix) * p.cs + c0 + 4 * c4;
+            if constexpr (X16) {
+                xr[u] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                if (ok) xr[u] = *reinterpret_cast<const bf16x4*>(x16 + o);
+            } else {
+                xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) xr[u] = *reinterpret_cast<const float4*>(p.x + o);
+            }
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int i = tid + 256 * u, px = i >> 4, n4 = i & 15;
             const int ly = px / TX, lx = px - ly * TX;
             const int iy = y0 + ly, ix = x0 + lx;
-            gr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy < p.H && ix < p.W)
-                gr[u] = *reinterpret_cast<const float4*>(p.dz + (((size_t)b * p.H + iy) * p.W + ix) * p.cout + co0 + 4 * n4);
+            const bool ok = iy < p.H && ix < p.W;
+            const size_t o = (((size_t)b * p.H + iy) * p.W + ix) * p.cout + co0 + 4 * n4;
+            if constexpr (G16) {
+                gr[u] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                if (ok) gr[u] = *reinterpret_cast<const bf16x4*>(g16 + o);
+            } else {
+                gr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) gr[u] = *reinterpret_cast<const float4*>(p.dz + o);
+            }
         }
     };
     auto commit = [&]() {
@@ -1519,14 +1549,16 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
             const int i = tid + 256 * u, px = i >> 4, c4 = i & 15;
             if (px >= PATCH) continue;
             bf16x4 h;
-            h[0] = (bf16_t)xr[u].x; h[1] = (bf16_t)xr[u].y; h[2] = (bf16_t)xr[u].z; h[3] = (bf16_t)xr[u].w;
+            if constexpr (X16) h = xr[u];
+            else { h[0] = (bf16_t)xr[u].x; h[1] = (bf16_t)xr[u].y; h[2] = (bf16_t)xr[u].z; h[3] = (bf16_t)xr[u].w; }
             *reinterpret_cast<bf16x4*>(ximg + px * WRS + 4 * c4) = h;
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int i = tid + 256 * u, px = i >> 4, n4 = i & 15;
             bf16x4 h;
-            h[0] = (bf16_t)gr[u].x; h[1] = (bf16_t)gr[u].y; h[2] = (bf16_t)gr[u].z; h[3] = (bf16_t)gr[u].w;
+            if constexpr (G16) h = gr[u];
+            else { h[0] = (bf16_t)gr[u].x; h[1] = (bf16_t)gr[u].y; h[2] = (bf16_t)gr[u].z; h[3] = (bf16_t)gr[u].w; }
             *reinterpret_cast<bf16x4*>(gimg + px * WRS + 4 * n4) = h;
         }
     };
@@ -1584,6 +1616,7 @@ using ig::TcArgs;
 using ig::tc_outpix;
 
 // forward: block = 128 input pixels x 64 output channels x 4 parities; K = Cin in chunks of 32
+template <bool X16>      // X16: the input is stored as bf16
 __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t* __restrict__ w16) {
     __shared__ __attribute__((aligned(16))) bf16_t a_lds[128 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t b_lds[4 * 64 * RS];
@@ -1602,10 +1635,15 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + px < p.npix) v = *reinterpret_cast<const float4*>(p.in + (size_t)(p0 + px) * p.cin + cc + 4 * c4);
             bf16x4 h;
-            h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+            if constexpr (X16) {
+                h = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                if (p0 + px < p.npix) h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.in) + (size_t)(p0 + px) * p.cin + cc + 4 * c4);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p0 + px < p.npix) v = *reinterpret_cast<const float4*>(p.in + (size_t)(p0 + px) * p.cin + cc + 4 * c4);
+                h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+            }
             *reinterpret_cast<bf16x4*>(a_lds + px * RS + 4 * c4) = h;
         }
 #pragma unroll
@@ -1648,6 +1686,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t
 
 // data gradient: din[p][ci] = sum_{ae,co} dout[out(p,ae)][co] * W[ae][co][ci]; block = 128 pixels x 64 input channels,
 // K = 4 x Cout in chunks of 32; w16 = [ae][ci][co] (K = co contiguous)
+template <bool G16>      // G16: dout is stored as bf16
 __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16_t* __restrict__ w16) {
     __shared__ __attribute__((aligned(16))) bf16_t a_lds[128 * RS];
     __shared__ __attribute__((aligned(16))) bf16_t b_lds[64 * RS];
@@ -1658,16 +1697,23 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 ar[4];
+    using AR = std::conditional_t<G16, bf16x4, float4>;
+    AR ar[4];
     u32x4 br;
     auto issue = [&](int kc) {
         const int ae = kc / p.cout, cc = kc - ae * p.cout;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
-            ar[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + px < p.npix)
-                ar[u] = *reinterpret_cast<const float4*>(p.dout + tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + cc + 4 * c4);
+            const bool ok = p0 + px < p.npix;
+            const size_t o = ok ? tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + cc + 4 * c4 : 0;
+            if constexpr (G16) {
+                ar[u] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                if (ok) ar[u] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.dout) + o);
+            } else {
+                ar[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) ar[u] = *reinterpret_cast<const float4*>(p.dout + o);
+            }
         }
         br = *reinterpret_cast<const u32x4*>(w16 + ((size_t)ae * p.cin + n0 + (tid >> 2)) * p.cout + cc + 8 * (tid & 3));
     };
@@ -1679,7 +1725,8 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
             bf16x4 h;
-            h[0] = (bf16_t)ar[u].x; h[1] = (bf16_t)ar[u].y; h[2] = (bf16_t)ar[u].z; h[3] = (bf16_t)ar[u].w;
+            if constexpr (G16) h = ar[u];
+            else { h[0] = (bf16_t)ar[u].x; h[1] = (bf16_t)ar[u].y; h[2] = (bf16_t)ar[u].z; h[3] = (bf16_t)ar[u].w; }
             *reinterpret_cast<bf16x4*>(a_lds + px * RS + 4 * c4) = h;
         }
         *reinterpret_cast<u32x4*>(b_lds + (tid >> 2) * RS + 8 * (tid & 3)) = br;
@@ -1714,6 +1761,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16
 
 // weight gradient: dW[ae][co][ci] = sum_p dout[out(p,ae)][co] * in[p][ci]; block = 64 co x 64 ci x 4 parities, persistent
 // over tiles of 128 input pixels (K); same staging / transposing-read scheme as k_igb_wgrad64.
+template <bool X16, bool G16>
 __global__ __launch_bounds__(256, 1) void k_igb_tconv_wgrad64(TcArgs p) {
     __shared__ __attribute__((aligned(16))) bf16_t ximg[128 * WRS];
     __shared__ __attribute__((aligned(16))) bf16_t gimg[4 * 128 * WRS];
@@ -1732,26 +1780,46 @@ __global__ __launch_bounds__(256, 1) void k_igb_tconv_wgrad64(TcArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[ae][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float4 xr[8], gr[4][8];
+    using XR = std::conditional_t<X16, bf16x4, float4>;
+    using GR = std::conditional_t<G16, bf16x4, float4>;
+    XR xr[8];
+    GR gr[4][8];
+    const bf16x4 zero4 = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
     auto issue = [&](int tile) {
         const int p0 = tile * 128;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = tid + 256 * u, px = i >> 4, c4 = i & 15;
             const bool ok = p0 + px < p.npix;
-            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) xr[u] = *reinterpret_cast<const float4*>(p.in + (size_t)(p0 + px) * p.cin + n0 + 4 * c4);
+            const size_t ox = (size_t)(p0 + px) * p.cin + n0 + 4 * c4;
+            if constexpr (X16) {
+                xr[u] = zero4;
+                if (ok) xr[u] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.in) + ox);
+            } else {
+                xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) xr[u] = *reinterpret_cast<const float4*>(p.in + ox);
+            }
 #pragma unroll
             for (int ae = 0; ae < 4; ++ae) {
-                gr[ae][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) gr[ae][u] = *reinterpret_cast<const float4*>(p.dout + tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + co0 + 4 * c4);
+                const size_t og = ok ? tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + co0 + 4 * c4 : 0;
+                if constexpr (G16) {
+                    gr[ae][u] = zero4;
+                    if (ok) gr[ae][u] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.dout) + og);
+                } else {
+                    gr[ae][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) gr[ae][u] = *reinterpret_cast<const float4*>(p.dout + og);
+                }
             }
         }
     };
-    auto cvt = [](const float4& v) {
-        bf16x4 h;
-        h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
-        return h;
+    auto cvt = [](const auto& v) {
+        if constexpr (std::is_same_v<std::decay_t<decltype(v)>, bf16x4>) {
+            return v;
+        } else {
+            bf16x4 h;
+            h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+            return h;
+        }
     };
     auto commit = [&]() {
 #pragma unroll
@@ -1842,6 +1910,69 @@ static bool use_bf16(const Model* m, const Op& o) {
 bool ig_tconv_supported(const Model* m, const Op& o);
 static bool use_bf16_tc(const Model* m, const Op& o) {
     return m->desc.dtype == DNNCA_BF16 && o.inA.d.C % 64 == 0 && o.out.d.C % 64 == 0;
+}
+
+// Which tensors are stored as bf16 (View::h)?  Under dtype bf16 the 64-channel conv / transposed-conv kernels round their
+// operands to bf16 while staging them, so a tensor whose every reader is one of those kernels can live in HBM as bf16 with
+// bit-identical results: the outputs of BatchNorm layers that feed only such kernels (and the fused max-pool, which records
+// the positions of its maxima for the backward pass), and the conv-output gradients the BatchNorm backward hands to them.
+int ig_plan_half(Model* m) {
+    if (m->desc.dtype != DNNCA_BF16 || (m->desc.flags & 1) || getenv("DNNCA_NO_HALF")) return DNNCA_OK;
+    const double MB = m->desc.max_batch;
+    auto conv_ok = [&](const Op& c) {     // forward, data gradient and weight gradient all take the 64-channel bf16 kernels
+        if (!ig_conv_supported(m, c) || !use_bf16(m, c)) return false;
+        const int CA = c.inA.d.C, CB = c.inB.d.C, CO = c.out.d.C;
+        if (CA % 64 || CB % 64 || CO % 64) return false;
+        const int cmax = CA > CB ? (CA > CO ? CA : CO) : (CB > CO ? CB : CO);
+        return MB * c.out.d.H * c.out.d.W * cmax * 4.0 < 2.0e9 && 9.0 * CO * (CA + CB) * 4.0 < 2.0e9;      // conv3_path()
+    };
+    std::map<float*, bool> hd, hg;
+    for (const Op& bn : m->ops) {
+        if (bn.type != OP_BN || !fast_bn_supported(m, bn) || !dense(bn.out.d) || !dense(bn.inA.g)) continue;
+        bool ok = true;
+        int users = 0;
+        for (const Op& c : m->ops) {
+            const bool a = c.inA.d.C && c.inA.d.p == bn.out.d.p, b = c.type == OP_CONV && c.inB.d.C && c.inB.d.p == bn.out.d.p;
+            if (!a && !b) continue;
+            ++users;
+            if (c.type == OP_CONV) ok = ok && conv_ok(c);
+            else if (c.type == OP_TCONV) ok = ok && ig_tconv_supported(m, c) && use_bf16_tc(m, c);
+            else if (c.type == OP_POOL) ok = ok && fast_bn_pool_fusable(m, bn, c) && dense(c.inA.g) && dense(c.out.g) && !c.maskA;
+            else ok = false;
+        }
+        if (ok && users) hd[bn.out.d.p] = true;
+        // the gradient this BN's backward writes: read only by the backward of the op that produced the BN's input
+        if (bn.accA) continue;
+        for (const Op& c : m->ops) {
+            if (c.out.d.p != bn.inA.d.p || !c.out.d.C) continue;
+            const bool pre = c.type != OP_CONV || c.alpha < 0.f || c.premasked;      // nobody rewrites it in f32 (g_act_bwd)
+            if ((c.type == OP_CONV && conv_ok(c) && c.need_din && pre) || (c.type == OP_TCONV && ig_tconv_supported(m, c) && use_bf16_tc(m, c)))
+                hg[bn.inA.g.p] = true;
+        }
+    }
+    // both sources of a conv are staged by the same code path
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (const Op& c : m->ops) {
+            if (c.type != OP_CONV || !c.inB.d.C) continue;
+            const bool a = hd.count(c.inA.d.p) && hd[c.inA.d.p], b = hd.count(c.inB.d.p) && hd[c.inB.d.p];
+            if (a != b) { hd[c.inA.d.p] = false; hd[c.inB.d.p] = false; changed = true; }
+        }
+    }
+    auto mark = [&](T& t) {
+        if (!t.d.C) return;
+        if (hd.count(t.d.p) && hd[t.d.p]) t.d.h = 1;
+        if (hg.count(t.g.p) && hg[t.g.p]) t.g.h = 1;
+    };
+    for (Op& o : m->ops) {
+        mark(o.inA); mark(o.inB); mark(o.out);
+        if (o.type == OP_POOL && o.inA.d.h && !o.pool_idx) {     // the backward pass cannot fall back on comparing values
+            void* ix = nullptr;
+            DN_TRY(m->alloc(&ix, (size_t)m->desc.max_batch * o.out.d.H * o.out.d.W * o.out.d.C));
+            o.pool_idx = (unsigned char*)ix;
+        }
+    }
+    return DNNCA_OK;
 }
 
 int ig_prepare(Model* m) {
@@ -1951,7 +2082,10 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
         a2.tiles_y = (a.H + igb::T2 - 1) / igb::T2;
         const unsigned nblocks = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / 64));
         const unsigned g = nblocks < 256u ? nblocks : 256u;
-        LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE>), dim3(g), dim3(256), 0, m->stream, a2, w16));
+        if (a.src_half)
+            LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE, true>), dim3(g), dim3(256), 0, m->stream, a2, w16));
+        else
+            LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE, false>), dim3(g), dim3(256), 0, m->stream, a2, w16));
         return;
     }
     dim3 grid(a.tiles_x * a.tiles_y * a.B, cout / (16 * nn));
@@ -1971,6 +2105,7 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
     a.tiles_x = (a.W + ig::TX - 1) / ig::TX;
     a.tiles_y = (a.H + ig::TY - 1) / ig::TY;
     a.alpha = o.alpha;
+    a.src_half = o.inA.d.h;          // ig_plan_half keeps both sources of a conv in the same format
     if (bn_next && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
         // the BatchNorm behind this conv takes its batch statistics from the conv's epilogue
         const int rows = conv3_rows(a);
@@ -1982,6 +2117,7 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
             bn_next->fused_stats_rows = rows;
         }
     }
+    if (a.src_half && !(use_bf16(m, o) && conv3_path(a, o.out.d.C, true))) return false;      // cannot happen (ig_plan_half); the caller reports it
     if (use_bf16(m, o)) {
         IgPlan& pl = g_ig[m];
         launch_igb<0>(m, a, pl.wf + o.w_off, o.out.d.C, "igb_conv_fwd", bytes, flops);
@@ -2044,8 +2180,12 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             int ps = (256 + combos64 - 1) / combos64;
             if (ps > ntiles) ps = ntiles;
             w.psplit = ps < 1 ? 1 : ps;
-            LAUNCH(m, "igb_wgrad64", bb, ff,
-                   hipLaunchKernelGGL(igb::k_igb_wgrad64, dim3(w.psplit, w.cs / 64, CO / 64), dim3(256), 0, m->stream, w));
+            const dim3 g64(w.psplit, w.cs / 64, CO / 64);
+            const bool xh = (s == 0 ? o.inA.d.h : o.inB.d.h) != 0, gh = o.out.g.h != 0;
+#define WG64(XH, GH) LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad64<XH, GH>), g64, dim3(256), 0, m->stream, w))
+            if (xh) { if (gh) WG64(true, true); else WG64(true, false); }
+            else { if (gh) WG64(false, true); else WG64(false, false); }
+#undef WG64
         } else if (!use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (w.cs > CO ? w.cs : CO) * 4.0 < 2.0e9 &&
                    !getenv("DNNCA_WGRAD1")) {
             const int mw = w.cs % 64 == 0 ? 4 : (w.cs % 32 == 0 ? 2 : 1);
@@ -2074,6 +2214,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
     if (o.need_din) {
         ig::ConvArgs a{};
         a.src[0] = o.out.g.p; a.c_src0 = CO; a.c_src1 = 0;
+        a.src_half = o.out.g.h;
         a.w = pl.flipped + o.w_off;
         a.dst[0] = o.inA.g.p; a.dst[1] = o.inB.g.p;
         a.n_dst0 = CA; a.n_dst1 = CB;
@@ -2121,8 +2262,11 @@ bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
     ig::TcArgs a = tc_args(m, B, o);
     if (use_bf16_tc(m, o)) {
         IgPlan& pl = g_ig[m];
-        LAUNCH(m, "igb_tconv_fwd", bytes, flops,
-               hipLaunchKernelGGL(igb::k_igb_tconv_fwd, dim3((a.npix + 127) / 128, a.cout / 64), dim3(256), 0, m->stream, a, pl.wf + o.w_off));
+        const dim3 grid((a.npix + 127) / 128, a.cout / 64);
+        if (o.inA.d.h)
+            LAUNCH(m, "igb_tconv_fwd", bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_fwd<true>, grid, dim3(256), 0, m->stream, a, pl.wf + o.w_off));
+        else
+            LAUNCH(m, "igb_tconv_fwd", bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_fwd<false>, grid, dim3(256), 0, m->stream, a, pl.wf + o.w_off));
         return true;
     }
     const int nn = pick_nn(a.cout);
@@ -2142,10 +2286,16 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
         int ps = (256 + combos - 1) / combos;
         if (ps > ntiles) ps = ntiles;
         a.psplit = ps < 1 ? 1 : ps;
-        LAUNCH(m, "igb_tconv_wgrad", out_bytes + in_bytes, flops,
-               hipLaunchKernelGGL(igb::k_igb_tconv_wgrad64, dim3(a.psplit, a.cout / 64, a.cin / 64), dim3(256), 0, m->stream, a));
-        LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops,
-               hipLaunchKernelGGL(igb::k_igb_tconv_dgrad, dim3((a.npix + 127) / 128, a.cin / 64), dim3(256), 0, m->stream, a, pl.wd + o.w_off));
+        const dim3 gw(a.psplit, a.cout / 64, a.cin / 64), gd((a.npix + 127) / 128, a.cin / 64);
+        const bool xh = o.inA.d.h != 0, gh = o.out.g.h != 0;
+#define TW64(XH, GH) LAUNCH(m, "igb_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((igb::k_igb_tconv_wgrad64<XH, GH>), gw, dim3(256), 0, m->stream, a))
+        if (xh) { if (gh) TW64(true, true); else TW64(true, false); }
+        else { if (gh) TW64(false, true); else TW64(false, false); }
+#undef TW64
+        if (gh)
+            LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_dgrad<true>, gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
+        else
+            LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_dgrad<false>, gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
         return true;
     }
     if ((double)a.npix * 4.0 * a.cout * 4.0 < 2.0e9 && (double)a.npix * a.cin * 4.0 < 2.0e9 && !getenv("DNNCA_TCWGRAD1")) {

@@ -621,6 +621,7 @@ __global__ __launch_bounds__(1024) void k_bn_fold_bwd(int C, int nb, const float
     dbeta[c] += (float)b;
 }
 
+template <bool YH>      // YH: y is stored as bf16
 __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* __restrict__ x, float* __restrict__ y, int C,
                                                        int yps, const float* __restrict__ coef) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -631,11 +632,13 @@ __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* _
     const float4 sc = *reinterpret_cast<const float4*>(coef + 4 * cq), sh = *reinterpret_cast<const float4*>(coef + C + 4 * cq);
     float4 o;
     o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
-    *reinterpret_cast<float4*>(y + p * yps + 4 * cq) = o;
+    if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + p * yps + 4 * cq) = to_bf16x4(o);
+    else *reinterpret_cast<float4*>(y + p * yps + 4 * cq) = o;
 }
 
 // BatchNorm apply + the MaxPool2D([2,2], 2) that follows it (components.py:54,59): one thread owns a 4-channel group of a 2 x 2
 // pixel window, writes the four normalised pixels and their maximum -- the pool pass never re-reads the normalised tensor.
+template <bool YH>
 __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const float* __restrict__ x, float* __restrict__ y,
                                                             float* __restrict__ pooled, unsigned* __restrict__ idx, int C, int H,
                                                             int W, const float* __restrict__ coef) {
@@ -657,7 +660,8 @@ __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const 
         const float4 v = *reinterpret_cast<const float4*>(x + o);
         float4 r;
         r.x = fmaf(v.x, sc.x, sh.x); r.y = fmaf(v.y, sc.y, sh.y); r.z = fmaf(v.z, sc.z, sh.z); r.w = fmaf(v.w, sc.w, sh.w);
-        *reinterpret_cast<float4*>(y + o) = r;
+        if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + o) = to_bf16x4(r);
+        else *reinterpret_cast<float4*>(y + o) = r;
         if (k == 0) mx = r;
         else {
             if (r.x > mx.x) { mx.x = r.x; where = (where & 0xffffff00u) | (unsigned)k; }
@@ -737,6 +741,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
     }
 }
 
+template <bool DH>      // DH: dx is stored as bf16 (never accumulated into)
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dx, int C, int dps, int acc,
                                                            const float* __restrict__ coef, const float* __restrict__ gamma,
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
     r.z = g.z * inv.z * (d.z - inv_n * (db.z + (v.z - mean.z) * inv.z * dg.z));
     r.w = g.w * inv.w * (d.w - inv_n * (db.w + (v.w - mean.w) * inv.w * dg.w));
     float4* o = reinterpret_cast<float4*>(dx) + i;
-    if (acc) {
+    if (!DH && acc) {
         const float4 t = *o;
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
     }
@@ -765,7 +770,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
         r.x *= v.x > 0.f ? 1.0f : alpha; r.y *= v.y > 0.f ? 1.0f : alpha;
         r.z *= v.z > 0.f ? 1.0f : alpha; r.w *= v.w > 0.f ? 1.0f : alpha;
     }
-    *o = r;
+    if (DH) reinterpret_cast<hbf16x4*>(dx)[i] = to_bf16x4(r);
+    else *o = r;
 }
 
 // partials table shared by all BN ops of a model (stream-ordered use); grown on demand
@@ -832,15 +838,25 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
             if (m->alloc(&ix, (size_t)m->desc.max_batch * pool->out.d.H * pool->out.d.W * C) == DNNCA_OK) pool->pool_idx = (unsigned char*)ix;
         }
         pool->pool_idx_valid = m->dry || pool->pool_idx != nullptr;     // the dry run lists the launches of the real one
-        LAUNCH(m, "bn_apply_pool", 2.25 * tb, tb / 2,
-               hipLaunchKernelGGL(k_bn_apply_pool_fast, dim3((unsigned)((n4 / 4 + 255) / 256)), dim3(256), 0, m->stream, n4 / 4,
-                                  o.inA.d.p, o.out.d.p, pool->out.d.p, reinterpret_cast<unsigned*>(pool->pool_idx), C, o.inA.d.H,
-                                  o.inA.d.W, o.coef));
+        const dim3 grid((unsigned)((n4 / 4 + 255) / 256));
+        unsigned* ix = reinterpret_cast<unsigned*>(pool->pool_idx);
+        if (o.out.d.h)
+            LAUNCH(m, "bn_apply_pool", 1.75 * tb, tb / 2,
+                   hipLaunchKernelGGL(k_bn_apply_pool_fast<true>, grid, dim3(256), 0, m->stream, n4 / 4, o.inA.d.p, o.out.d.p,
+                                      pool->out.d.p, ix, C, o.inA.d.H, o.inA.d.W, o.coef));
+        else
+            LAUNCH(m, "bn_apply_pool", 2.25 * tb, tb / 2,
+                   hipLaunchKernelGGL(k_bn_apply_pool_fast<false>, grid, dim3(256), 0, m->stream, n4 / 4, o.inA.d.p, o.out.d.p,
+                                      pool->out.d.p, ix, C, o.inA.d.H, o.inA.d.W, o.coef));
         return true;
     }
-    LAUNCH(m, "bn_apply", 2 * tb, tb / 2,
-           hipLaunchKernelGGL(k_bn_apply_fast, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, m->stream, n4, o.inA.d.p,
-                              o.out.d.p, C, o.out.d.ps, o.coef));
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (o.out.d.h)
+        LAUNCH(m, "bn_apply", 1.5 * tb, tb / 2,
+               hipLaunchKernelGGL(k_bn_apply_fast<true>, grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.d.p, C, o.out.d.ps, o.coef));
+    else
+        LAUNCH(m, "bn_apply", 2 * tb, tb / 2,
+               hipLaunchKernelGGL(k_bn_apply_fast<false>, grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.d.p, C, o.out.d.ps, o.coef));
     return true;
 }
 
@@ -863,10 +879,17 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
            hipLaunchKernelGGL(k_bn_fold_bwd, dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, part, m->g + o.w_off,
                               m->g + o.b_off));
     const size_t n4 = npix * (C / 4);
-    LAUNCH(m, "bn_bwd_apply", 3 * tb, 2 * tb,
-           hipLaunchKernelGGL(k_bn_bwd_apply_fast, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, m->stream, n4, o.inA.d.p,
-                              o.out.g.p, o.inA.g.p, C, o.out.g.ps, (int)o.accA, o.coef, m->p + o.w_off, m->g + o.w_off,
-                              m->g + o.b_off, (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha));
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (o.inA.g.h)
+        LAUNCH(m, "bn_bwd_apply", 2.5 * tb, 2 * tb,
+               hipLaunchKernelGGL(k_bn_bwd_apply_fast<true>, grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.g.p, o.inA.g.p, C,
+                                  o.out.g.ps, 0, o.coef, m->p + o.w_off, m->g + o.w_off, m->g + o.b_off,
+                                  (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha));
+    else
+        LAUNCH(m, "bn_bwd_apply", 3 * tb, 2 * tb,
+               hipLaunchKernelGGL(k_bn_bwd_apply_fast<false>, grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.g.p, o.inA.g.p, C,
+                                  o.out.g.ps, (int)o.accA, o.coef, m->p + o.w_off, m->g + o.w_off, m->g + o.b_off,
+                                  (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha));
     return true;
 }
 

@@ -319,6 +319,7 @@ int Model::build() {
     }
 
     fast_plan_masks(this);
+    DN_TRY(ig_plan_half(this));
 
     // flat buffers
     DN_TRY(alloc((void**)&p, (size_t)nT * 4));
@@ -359,6 +360,13 @@ int Model::build() {
 // ---------------------------------------------------------------------------------------------- forward
 static inline double nelem(int B, const View& v) { return (double)B * v.H * v.W * v.C; }
 
+// the untuned kernels read and write f32 only: a tensor stored as bf16 (View::h) must have been taken by a tuned kernel
+static bool all_f32(const Op& o) {
+    if (!(o.inA.d.h | o.inA.g.h | o.inB.d.h | o.inB.g.h | o.out.d.h | o.out.g.h)) return true;
+    set_error("internal: %s has a bf16-stored operand but no tuned kernel took it", o.name.c_str());
+    return false;
+}
+
 int Model::forward(const float* x_dev, int B, bool training) {
     if (B < 1 || B > desc.max_batch) { set_error("batch %d outside [1, max_batch=%d]", B, desc.max_batch); return DNNCA_EINVAL; }
     last_batch = B;
@@ -391,6 +399,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 Op* bn_next = (training && oi + 1 < ops.size() && ops[oi + 1].type == OP_BN && ops[oi + 1].inA.d.p == o.out.d.p &&
                                fast_bn_supported(this, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
                 if (!generic && (fast_first_conv_fwd(this, B, o, bytes, flops) || ig_conv_fwd(this, B, o, bytes, flops, bn_next))) break;
+                if (!all_f32(o)) return DNNCA_ESTATE;
                 LAUNCH(this, "g_conv_fwd", bytes, flops,
                        g_conv_fwd(stream, B, o.inA.d, o.inB.d, p + o.w_off, p + o.b_off, o.out.d, o.k, o.alpha));
                 break;
@@ -404,6 +413,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                     if (bn_pool) pool_done = bn_pool;
                     break;
                 }
+                if (!all_f32(o)) return DNNCA_ESTATE;
                 if (training) {
                     if (!dry) HIP_TRY(hipMemsetAsync(o.ws, 0, (size_t)2 * C * 8, stream));
                     LAUNCH(this, "g_bn_stats_mean", tb, tb / 4, g_bn_stats_mean(stream, B, o.inA.d, o.ws));
@@ -419,6 +429,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 if (pool_done == &o) break;          // computed by the conv that produced its input
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
                 if (!generic && fast_pool_fwd(this, B, o, bytes)) break;
+                if (!all_f32(o)) return DNNCA_ESTATE;
                 LAUNCH(this, "g_pool_fwd", bytes, 0, g_pool_fwd(stream, B, o.inA.d, o.out.d, o.k));
                 break;
             }
@@ -426,6 +437,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
                 double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
                 if (!generic && (fast_tconv_fwd(this, B, o, bytes, flops) || ig_tconv_fwd(this, B, o, bytes, flops))) break;
+                if (!all_f32(o)) return DNNCA_ESTATE;
                 LAUNCH(this, "g_tconv_fwd", bytes, flops,
                        g_tconv_fwd(stream, B, o.inA.d, p + o.w_off, p + o.b_off, o.out.d, o.k));
                 break;
@@ -437,6 +449,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                     head_deferred = true;   // runs fused with the loss and its own backward (fast_head_train)
                     break;
                 }
+                if (!all_f32(o)) return DNNCA_ESTATE;
                 LAUNCH(this, "g_head_fwd", 4.0 * (nelem(B, o.inA.d) + npix), 2.0 * nelem(B, o.inA.d),
                        g_head_fwd(stream, B, o.inA.d, p + o.w_off, p + o.b_off, logits));
                 break;
@@ -507,6 +520,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
                     if (!generic && (fast_conv_bwd(this, B, o, ob, ib, flops) || fast_first_conv_bwd(this, B, o, ob, ib, flops) ||
                                      ig_conv_bwd(this, B, o, ob, ib, flops))) break;
+                    if (!all_f32(o)) return DNNCA_ESTATE;
                     if (o.maskA || o.maskB) { set_error("internal: masked conv gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     if (o.alpha >= 0.f && !o.premasked)
                         LAUNCH(this, "g_act_bwd", 3 * ob, ob / 4,
@@ -522,6 +536,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     double tb = 4.0 * nelem(B, o.inA.d);
                     double n = (double)B * o.inA.d.H * o.inA.d.W;
                     if (!generic && fast_bn_bwd(this, B, o)) break;
+                    if (!all_f32(o)) return DNNCA_ESTATE;
                     if (o.maskA) { set_error("internal: masked batch-norm gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     LAUNCH(this, "g_bn_bwd_reduce", 2 * tb, tb,
                            g_bn_bwd_reduce(stream, B, o.inA.d, o.out.g, o.coef, g + o.w_off, g + o.b_off));
@@ -533,6 +548,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 case OP_POOL: {
                     double bytes = 4.0 * (2 * nelem(B, o.inA.d) + 2 * nelem(B, o.out.d));
                     if (!generic && fast_pool_bwd(this, B, o, bytes)) break;
+                    if (!all_f32(o)) return DNNCA_ESTATE;
                     if (o.maskA) { set_error("internal: masked pool gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     LAUNCH(this, "g_pool_bwd", bytes, 0,
                            g_pool_bwd(stream, B, o.inA.d, o.out.d, o.out.g, o.inA.g, o.accA, o.k));
@@ -542,6 +558,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * nelem(B, o.inA.d);
                     double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
                     if (!generic && (fast_tconv_bwd(this, B, o, ob, ib, flops) || ig_tconv_bwd(this, B, o, ob, ib, flops))) break;
+                    if (!all_f32(o)) return DNNCA_ESTATE;
                     if (o.maskA) { set_error("internal: masked transposed-conv gradient has no tuned kernel"); return DNNCA_ESTATE; }
                     LAUNCH(this, "g_tconv_wgrad", ob + ib, flops,
                            g_tconv_wgrad(stream, B, o.inA.d, o.out.g, g + o.w_off, g + o.b_off, o.k));
