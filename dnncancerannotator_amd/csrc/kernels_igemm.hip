@@ -15,6 +15,15 @@
 
 namespace dnnca {
 
+// Division by a kernel-uniform divisor the persistent kernels repeat per tile: hipcc expands `/` into a ~25-instruction
+// dependent chain, which a kernel running one wave per SIMD cannot hide.  q = umulhi(n, ceil(2^32 / d)) is exact while
+// n * d < 2^32 (tile / unit / item counts are far below that).
+struct FastDiv {
+    unsigned d, m;
+    __device__ __forceinline__ explicit FastDiv(int dd) : d((unsigned)dd), m(dd > 1 ? (unsigned)(0xffffffffull / (unsigned)dd) + 1u : 0u) {}
+    __device__ __forceinline__ int div(int n) const { return d > 1 ? (int)__umulhi((unsigned)n, m) : n; }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace ig {
@@ -300,6 +309,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
     const int c0 = blockIdx.y * CIT, co0 = blockIdx.z * COT;
     const bool do_bias = p.dbias && blockIdx.y == 0 && wm == 0;
     const int tiles_y = (p.H + TYW - 1) / TYW;
+    const FastDiv d_tx(p.tiles_x), d_ty(tiles_y);
     const int ntiles = p.tiles_x * tiles_y * p.B;
     const size_t npix = (size_t)p.B * p.H * p.W;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(npix * p.cs * 4), WG_FLAGS);
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
     auto issue = [&](int tile) {               // tile >= ntiles: stage nothing (every offset out of range)
         const unsigned oob = tile < ntiles ? 0u : WG_OOB;
         tile = tile < ntiles ? tile : 0;
-        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % tiles_y, b = tile / (p.tiles_x * tiles_y);
+        const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x, b = d_ty.div(trow), by = trow - b * tiles_y;
         const int x0 = bx * TX, y0 = by * TYW;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
@@ -476,21 +486,23 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
     const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * 4), nbytes1 = (unsigned)(npix * p.c_src1 * 4);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((size_t)9 * nout * kin * 4), WG_FLAGS);
 
+    const FastDiv d_nco(nco), d_tx(p.tiles_x), d_ty(p.tiles_y), d_chunks(nchunks);
     struct Unit { int b, y0, x0, co0, tile; };
     auto unit_of = [&](int k) {
         const int id = blockIdx.x + k * gridDim.x;
         int tile, cot;
         if (xcd_map) {
-            const int xcd = id & 7, j = id >> 3;
-            cot = j % nco;
-            tile = (j / nco) * 8 + xcd;
+            const int xcd = id & 7, j = id >> 3, jq = d_nco.div(j);
+            cot = j - jq * nco;
+            tile = jq * 8 + xcd;
         } else {
-            cot = id % nco;
-            tile = id / nco;
+            tile = d_nco.div(id);
+            cot = id - tile * nco;
         }
         Unit u;
-        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y;
-        u.b = tile / (p.tiles_x * p.tiles_y);
+        const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x;
+        u.b = d_ty.div(trow);
+        const int by = trow - u.b * p.tiles_y;
         u.x0 = bx * F3T; u.y0 = by * F3T; u.co0 = cot * COT; u.tile = tile;
         return u;
     };
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
     auto stage_of = [&](int item) {
         const int valid = item < nitems;
         item = valid ? item : 0;
-        const int k = item / nchunks;
+        const int k = d_chunks.div(item);
         const Unit u = unit_of(k);
         Stage st;
         st.b = u.b; st.y0 = u.y0; st.x0 = u.x0; st.co0 = u.co0;
@@ -563,18 +575,18 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
         for (int v = 0; v < BU; ++v) issue_b(s1, v);
     }
     lds_barrier();
+    int it = 0;          // units outside, K chunks inside (see igb::k_igb_conv3)
 #pragma unroll 1
-    for (int it = 0; it < nitems; ++it) {
+    for (int k = 0; k < my_units; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* buf = lds + (it & 1) * BUF;
         float* other = lds + ((it & 1) ^ 1) * BUF;
-        const int k = it / nchunks, chunk = it - k * nchunks;
         const Stage nx = stage_of(it + 2);
-        if (chunk == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
         const float* a_lds = buf + ((4 * wave) * (F3T + 2) + m16) * F3AS + q;
         const float* b_lds = buf + ABUF + q * BS + m16;
         // step s = (dx = s / 4, K-step k4 = s % 4): 6 A words (rows 0..5) + 3 x NN B words (dy = 0..2)
@@ -606,8 +618,10 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
                         acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s & 1][r + dy], fb[s & 1][dy][j], acc[r][j], 0, 0, 0);
         }
         lds_barrier();
-        if (chunk == nchunks - 1) {
+    }
+        {
             const Unit u = unit_of(k);
+            float* buf = lds + ((it - 1) & 1) * BUF;
             float* o_lds = buf;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -1259,21 +1273,23 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * ESZ), nbytes1 = (unsigned)(npix * p.c_src1 * ESZ);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)w16, 0, (unsigned)((size_t)9 * nout * kin * 2), BUF_FLAGS);
 
+    const FastDiv d_nco(nco), d_tx(p.tiles_x), d_ty(p.tiles_y), d_chunks(nchunks);
     struct Unit { int b, y0, x0, co0, tile; };
     auto unit_of = [&](int k) {
         const int id = blockIdx.x + k * gridDim.x;
         int tile, cot;
         if (xcd_map) {              // ids congruent mod 8 share an XCD: keep a tile's channel blocks there
-            const int xcd = id & 7, j = id >> 3;
-            cot = j % nco;
-            tile = (j / nco) * 8 + xcd;
+            const int xcd = id & 7, j = id >> 3, jq = d_nco.div(j);
+            cot = j - jq * nco;
+            tile = jq * 8 + xcd;
         } else {
-            cot = id % nco;
-            tile = id / nco;
+            tile = d_nco.div(id);
+            cot = id - tile * nco;
         }
         Unit u;
-        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y;
-        u.b = tile / (p.tiles_x * p.tiles_y);
+        const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x;
+        u.b = d_ty.div(trow);
+        const int by = trow - u.b * p.tiles_y;
         u.x0 = bx * T2; u.y0 = by * T2; u.co0 = cot * 64; u.tile = tile;
         return u;
     };
@@ -1299,7 +1315,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     auto stage_of = [&](int item) {            // items past the end stage nothing: every offset is out of range
         const int valid = item < nitems;
         item = valid ? item : 0;
-        const int k = item / nchunks;
+        const int k = d_chunks.div(item);
         const Unit u = unit_of(k);
         Stage st;
         st.b = u.b; st.y0 = u.y0; st.x0 = u.x0; st.co0 = u.co0;
@@ -1360,18 +1376,20 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         }
     }
     lds_barrier();
+    // units outside, K chunks inside: the accumulators are plainly zeroed per unit (a conditional reset inside one flat
+    // item loop made hipcc shuffle all 64 accumulator registers through copies at the top of every item)
+    int it = 0;
 #pragma unroll 1
-    for (int it = 0; it < nitems; ++it) {
+    for (int k = 0; k < my_units; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         bf16_t* buf = lds + (it & 1) * BUF3;
         bf16_t* other = lds + ((it & 1) ^ 1) * BUF3;
-        const int k = it / nchunks, chunk = it - k * nchunks;
         const Stage nx = stage_of(it + 2);
-        if (chunk == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
         const bf16_t* a_lds = buf + ((4 * wave) * (T2 + 2) + m16) * RS + 8 * q;
         const bf16_t* b_lds = buf + PATCH2 * RS + m16 * RS + 8 * q;
         bf16x8 fa[2][6], fb[2][4];
@@ -1408,9 +1426,11 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
                     acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][r + dy], fb[s & 1][j], acc[r][j], 0, 0, 0);
         }
         lds_barrier();
-        if (chunk == nchunks - 1) {
+    }
+        {
             // ---- epilogue of unit k through the buffer that was just read
             const Unit u = unit_of(k);
+            bf16_t* buf = lds + ((it - 1) & 1) * BUF3;
             float* o_lds = reinterpret_cast<float*>(buf);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -1503,6 +1523,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
     for (int j = 0; j < 4; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int XU = (PATCH * 16 + 255) / 256, GU = TY * TX * 16 / 256;      // 12 and 8 float4 per thread
+    const FastDiv d_tx(p.tiles_x), d_ty(p.tiles_y);
     using XR = std::conditional_t<X16, bf16x4, float4>;
     using GR = std::conditional_t<G16, bf16x4, float4>;
     XR xr[XU];
@@ -1510,7 +1531,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
     const bf16_t* x16 = reinterpret_cast<const bf16_t*>(p.x);
     const bf16_t* g16 = reinterpret_cast<const bf16_t*>(p.dz);
     auto issue = [&](int tile) {
-        const int bx = tile % p.tiles_x, by = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+        const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x, b = d_ty.div(trow), by = trow - b * p.tiles_y;
         const int x0 = bx * TX, y0 = by * TY;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {

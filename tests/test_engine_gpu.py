@@ -250,6 +250,29 @@ def test_unet_big_bf16_contraction_against_oracle(gpu):
     m.close()
 
 
+def test_bf16_storage_of_rounded_tensors_is_transparent(gpu, monkeypatch):
+    """dtype bf16 keeps the tensors whose every reader rounds to bf16 anyway (BatchNorm outputs feeding the 64-channel conv
+    kernels, the conv-output gradients from the BatchNorm backward) as bf16 in HBM (ig_plan_half).  That must not change a
+    single bit of the forward pass; gradients may differ by the summation order of the float atomics only."""
+    opts = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', n_filters_first=64, n_downsample=2, bn=True)
+    x, y = O.synthetic_batch(2, 64, 64, 1)
+    res = []
+    for no_half in (False, True):
+        if no_half:
+            monkeypatch.setenv('DNNCA_NO_HALF', '1')
+        m = gpu.DeviceModel('unet', 1, 64, 64, 2, dtype='bf16', **opts)
+        m.init_glorot(seed=2)
+        plan_bytes = sum(b for k, b, f in m.plan() if k.startswith('bn_'))
+        _, lg = m.forward(x, training=True, return_logits=True)
+        m.train_step(x, y, 1e-3, m.loss_cfg(weight_mul=3.0))
+        res.append((plan_bytes, lg.copy(), m.get_grads().copy()))
+        m.close()
+    (bh, lh, gh), (bf, lf, gf) = res
+    assert bh < bf                       # the BatchNorm passes really write 2-byte elements
+    assert np.array_equal(lh, lf)
+    assert np.abs(gh - gf).max() <= 1e-5 * np.abs(gf).max()
+
+
 def test_cli_train_then_evaluate_on_tfrecords(gpu, tmp_path):
     """`python3 -m annotator train|evaluate` with the reference's YAML surface and .tfrecords exam files, in a child
     process (the documented drop-in invocation)."""
