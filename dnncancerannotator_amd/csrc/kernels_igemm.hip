@@ -35,38 +35,6 @@ constexpr int PATCH = (TY + 2) * (TX + 2);
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- BatchNorm statistics in the epilogue of the persistent forward conv kernels (see ConvArgs::bn_part).  The macros
-// expand inside the epilogue, where `val` is the float4 just stored for pixel (y, x) / channels 4 e4 .. (cw channels in
-// all, this unit's first channel cl), `prow` / `PPP` / `COT` the thread -> (pixel row, channel quad) map.
-// (The backward sums of a BatchNorm were tried in the consuming conv's data-gradient epilogue too: the extra read of the
-// normalised input there cost more than the reduction pass it replaced -- 2.1 -> 3.2 ms of dgrad against 0.7 ms saved.)
-#define BN_EPI_DECL                                                                                                     \
-    const bool bn_on = MODE == 0 && p.bn_part != nullptr;                                                                \
-    float bn_s[4] = {0.f, 0.f, 0.f, 0.f}, bn_q[4] = {0.f, 0.f, 0.f, 0.f};
-#define BN_EPI_ACC                                                                                                      \
-    if (bn_on) {                                                                                                         \
-        bn_s[0] += val.x; bn_s[1] += val.y; bn_s[2] += val.z; bn_s[3] += val.w;                                          \
-        bn_q[0] = fmaf(val.x, val.x, bn_q[0]); bn_q[1] = fmaf(val.y, val.y, bn_q[1]);                                    \
-        bn_q[2] = fmaf(val.z, val.z, bn_q[2]); bn_q[3] = fmaf(val.w, val.w, bn_q[3]);                                    \
-    }
-// partial row of this unit: [tile][2 cw]: first half sums, second half sums of squares
-#define BN_EPI_TAIL                                                                                                     \
-    if (bn_on) {                                                                                                         \
-        lds_barrier();                      /* every thread is done reading the output image */                        \
-        float* red = reinterpret_cast<float*>(buf);                                                                      \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                  \
-            red[prow * (2 * COT) + 4 * e4 + c] = bn_s[c];                                                                \
-            red[prow * (2 * COT) + COT + 4 * e4 + c] = bn_q[c];                                                          \
-        }                                                                                                                \
-        lds_barrier();                                                                                                   \
-        if (tid < 2 * COT) {                                                                                             \
-            float a = 0.f;                                                                                               \
-            for (int r = 0; r < PPP; ++r) a += red[r * (2 * COT) + tid];                                                 \
-            const int half = tid >= COT, c = half ? tid - COT : tid;                                                     \
-            p.bn_part[(size_t)u.tile * (2 * cw) + half * cw + cl + c] = a;                                               \
-        }                                                                                                                \
-    }
-
 struct ConvArgs {
     const float* src[2];     // dense NHWC sources; chunk cc comes from src[cc >= c_src0]
     int c_src0, c_src1;      // channels of the two sources (c_src1 = 0: one source)
@@ -83,6 +51,106 @@ struct ConvArgs {
     float* bn_part;          // [tile][2 * Cout] float partials (sum, sum of squares per channel); nullptr: none
     int src_half;            // the sources are stored as bf16 (View::h; k_igb_conv3 only)
 };
+
+// Epilogue of the persistent kernels (k_ig_conv3 / igb::k_igb_conv3), straight from the accumulator registers: lane (m16, q)
+// of wave w holds acc[r][j][i] = pixel (row 4w + r, column 4q + i) x channel 16j + m16 of the 16 x 16 tile, so one store
+// instruction writes four 64-byte channel runs.  (The earlier version transposed the tile through LDS to store 256-byte rows:
+// 64 LDS writes + 16 LDS reads per lane and up to five barriers cost as much as 1.7 K-chunks of MFMAs per tile.)
+//   MODE 0: + bias, activation; the BatchNorm behind the conv takes its batch statistics from here (ConvArgs::bn_part): per-lane
+//           sums over the lane's 16 pixels, the four q groups folded by two wave shuffles, the four waves through `red`
+//           ([4][2 COT] floats of LDS) -- one barrier;
+//   MODE 1: accumulate into dst and multiply by act'(mask tensor) as requested.
+// (The backward sums of a BatchNorm were tried in the data-gradient epilogue too: the extra read of the normalised input
+// there cost more than the reduction pass it replaced -- 2.1 -> 3.2 ms of dgrad against 0.7 ms saved.)
+template <int NN, int MODE>
+__device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0, int tile,
+                                               float* red) {
+    constexpr int COT = 16 * NN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int which = co0 >= p.n_dst0;
+    const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co0 - p.n_dst0 : co0;
+    float* dst = p.dst[which];
+    const bool bn_on = MODE == 0 && p.bn_part != nullptr;
+    float bias[NN], bs[NN], bq[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        bias[j] = (MODE == 0 && p.bias) ? p.bias[co0 + 16 * j + m16] : 0.f;
+        bs[j] = 0.f;
+        bq[j] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + 4 * wave + r;
+        if (y >= p.H) continue;                 // wave-uniform
+        float v[4][NN];
+        bool ok[4];
+        size_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = x0 + 4 * q + i;
+            ok[i] = x < p.W;
+            o[i] = (((size_t)b * p.H + y) * p.W + (ok[i] ? x : 0)) * cw + cl + m16;
+#pragma unroll
+            for (int j = 0; j < NN; ++j) v[i][j] = acc[r][j][i];
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NN; ++j) {
+                    float t = v[i][j] + bias[j];
+                    if (p.alpha >= 0.f) t = t > 0.f ? t : p.alpha * t;
+                    v[i][j] = t;
+                    if (bn_on && ok[i]) { bs[j] += t; bq[j] = fmaf(t, t, bq[j]); }
+                }
+        } else {
+            if (p.acc[which]) {
+                float t[4][NN];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j) t[i][j] = ok[i] ? dst[o[i] + 16 * j] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j) v[i][j] += t[i][j];
+            }
+            if (p.mask[which]) {
+                float t[4][NN];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j) t[i][j] = ok[i] ? p.mask[which][o[i] + 16 * j] : 1.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j) v[i][j] *= t[i][j] > 0.f ? 1.0f : p.alpha;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NN; ++j)
+                if (ok[i]) dst[o[i] + 16 * j] = v[i][j];
+    }
+    if (bn_on) {        // partial row of this unit: [tile][2 cw]: first half sums, second half sums of squares
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            bs[j] += __shfl_xor(bs[j], 16); bs[j] += __shfl_xor(bs[j], 32);
+            bq[j] += __shfl_xor(bq[j], 16); bq[j] += __shfl_xor(bq[j], 32);
+            if (q == 0) {
+                red[wave * (2 * COT) + 16 * j + m16] = bs[j];
+                red[wave * (2 * COT) + COT + 16 * j + m16] = bq[j];
+            }
+        }
+        lds_barrier();
+        if (tid < 2 * COT) {
+            const float a = (red[tid] + red[2 * COT + tid]) + (red[4 * COT + tid] + red[6 * COT + tid]);
+            const int half = tid >= COT, c = half ? tid - COT : tid;
+            p.bn_part[(size_t)tile * (2 * cw) + half * cw + cl + c] = a;
+        }
+    }
+}
 
 // MODE 0 forward, MODE 1 data gradient
 template <int NN, int MODE>
@@ -469,9 +537,9 @@ template <int NN, int MODE>
 __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
     constexpr int COT = 16 * NN, BS = COT + 16;                 // B row stride (floats): 16 (mod 32) banks
     constexpr int ABUF = F3PATCH * F3AS, BBUF = 9 * CK * BS;
-    constexpr int OSTR = COT + 4;
-    constexpr int BUF = (ABUF + BBUF + 16) > (256 * OSTR) ? (ABUF + BBUF + 16) : (256 * OSTR);   // floats per LDS buffer
+    constexpr int BUF = ABUF + BBUF + 16;                       // floats per LDS buffer
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    __shared__ float bn_red[4 * 2 * COT];       // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4;
     const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
@@ -621,52 +689,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
     }
         {
             const Unit u = unit_of(k);
-            float* buf = lds + ((it - 1) & 1) * BUF;
-            float* o_lds = buf;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < NN; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o_lds[((4 * wave + r) * F3T + 4 * q + i) * OSTR + 16 * j + m16] = acc[r][j][i];
-            lds_barrier();
-            const int which = u.co0 >= p.n_dst0;
-            const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? u.co0 - p.n_dst0 : u.co0;
-            float* dst = p.dst[which];
-            constexpr int TPP = 4 * NN, PPP = 256 / TPP;          // threads per pixel, pixels per pass
-            const int e4 = tid % TPP, prow = tid / TPP;
-            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE == 0 && p.bias) bias = *reinterpret_cast<const float4*>(p.bias + u.co0 + 4 * e4);
-            BN_EPI_DECL
-#pragma unroll 4
-            for (int v = 0; v < TPP; ++v) {
-                const int px = prow + PPP * v, ly = px >> 4, lx = px & 15;
-                const int y = u.y0 + ly, x = u.x0 + lx;
-                if (y >= p.H || x >= p.W) continue;
-                float4 val = *reinterpret_cast<const float4*>(o_lds + px * OSTR + 4 * e4);
-                const size_t o = (((size_t)u.b * p.H + y) * p.W + x) * cw + cl + 4 * e4;
-                if (MODE == 0) {
-                    val.x += bias.x; val.y += bias.y; val.z += bias.z; val.w += bias.w;
-                    if (p.alpha >= 0.f) {
-                        val.x = val.x > 0.f ? val.x : p.alpha * val.x; val.y = val.y > 0.f ? val.y : p.alpha * val.y;
-                        val.z = val.z > 0.f ? val.z : p.alpha * val.z; val.w = val.w > 0.f ? val.w : p.alpha * val.w;
-                    }
-                } else {
-                    if (p.acc[which]) {
-                        const float4 t = *reinterpret_cast<const float4*>(dst + o);
-                        val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w;
-                    }
-                    if (p.mask[which]) {
-                        const float4 mk = *reinterpret_cast<const float4*>(p.mask[which] + o);
-                        val.x *= mk.x > 0.f ? 1.0f : p.alpha; val.y *= mk.y > 0.f ? 1.0f : p.alpha;
-                        val.z *= mk.z > 0.f ? 1.0f : p.alpha; val.w *= mk.w > 0.f ? 1.0f : p.alpha;
-                    }
-                }
-                *reinterpret_cast<float4*>(dst + o) = val;
-                BN_EPI_ACC
-            }
-            BN_EPI_TAIL
-            lds_barrier();
+            conv3_epilogue<NN, MODE>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
         }
     }
 }
@@ -1235,6 +1258,19 @@ __global__ __launch_bounds__(256) void k_igb_wgrad(ig::WgArgs p) {
     }
 }
 
+// phase stamps of k_igb_conv3 (tuning builds only: DNNCA_TUNING=1 python -m dnncancerannotator_amd.build; tools/ig_stamps.py)
+#ifdef DNNCA_TUNING
+__device__ unsigned long long g_ig_stamps[64 * 8];
+__device__ __forceinline__ unsigned long long ig_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define IGSTAMP(item, ph) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (item) < 64) g_ig_stamps[(item) * 8 + (ph)] = ig_now(); } while (0)
+#else
+#define IGSTAMP(item, ph) do { } while (0)
+#endif
+
 constexpr int T2 = 16;                              // tile edge of the persistent forward / data-gradient kernel
 constexpr int PATCH2 = (T2 + 2) * (T2 + 2);         // 324 staged pixels
 
@@ -1247,10 +1283,8 @@ constexpr int PATCH2 = (T2 + 2) * (T2 + 2);         // 324 staged pixels
 //   fragments are double-buffered in registers: the LDS reads of tap step s+1 are issued before the 16 MFMAs of step s;
 //   taps are walked dx-major so that the six A rows of a dx serve its three dy taps (18 instead of 24 reads per 48 MFMAs);
 //   global loads are raw buffer loads: out-of-image patch pixels get an out-of-range offset and come back as zeros, no
-//   branches; epilogue through LDS (the buffer just read): every pixel's 64 output channels leave as one 256-byte row of
-//   float4 stores (bias + activation, or accumulate + act' mask for the data gradient, on float4s as well).
+//   branches; the epilogue stores straight from the accumulators (ig::conv3_epilogue) and needs no LDS image and no barrier.
 constexpr int BUF3 = (PATCH2 + 9 * 64) * RS + 64;   // bf16 elements per LDS buffer: A patch + 9-tap weight slab (72,000 B) + a dump row for the idle lanes of the last A element
-constexpr int OSTR = 68;                            // floats per pixel row of the epilogue image
 constexpr unsigned BUF_FLAGS = 0x00020000u;         // raw buffer descriptor word 3 (gfx9 family)
 constexpr unsigned OOB = 0x80000000u;               // beyond every tensor here: the buffer load returns zeros
 
@@ -1258,6 +1292,7 @@ constexpr unsigned OOB = 0x80000000u;               // beyond every tensor here:
 template <int MODE, bool A16>
 __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* __restrict__ w16) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * BUF3];
+    __shared__ float bn_red[4 * 2 * 64];        // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4;
     const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
@@ -1389,7 +1424,9 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         bf16_t* buf = lds + (it & 1) * BUF3;
         bf16_t* other = lds + ((it & 1) ^ 1) * BUF3;
+        IGSTAMP(it, 0);
         const Stage nx = stage_of(it + 2);
+        IGSTAMP(it, 1);
         const bf16_t* a_lds = buf + ((4 * wave) * (T2 + 2) + m16) * RS + 8 * q;
         const bf16_t* b_lds = buf + PATCH2 * RS + m16 * RS + 8 * q;
         bf16x8 fa[2][6], fb[2][4];
@@ -1397,9 +1434,14 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         for (int rr = 0; rr < 6; ++rr) fa[0][rr] = *reinterpret_cast<const bf16x8*>(a_lds + (rr * (T2 + 2)) * RS);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(b_lds + (16 * j) * RS);
+        IGSTAMP(it, 2);
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int g = s / 3, dy = s % 3;            // tap (dy, dx = g): weight slab index dy * 3 + g
+#ifdef DNNCA_TUNING
+            if (s == 3) IGSTAMP(it, 3);
+            if (s == 6) IGSTAMP(it, 4);
+#endif
             if (s + 1 < 9) {                            // fragments of the next step
                 const int g1 = (s + 1) / 3, dy1 = (s + 1) % 3;
                 if (dy1 == 0) {
@@ -1425,58 +1467,14 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
                 for (int j = 0; j < 4; ++j)
                     acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][r + dy], fb[s & 1][j], acc[r][j], 0, 0, 0);
         }
+        IGSTAMP(it, 5);
         lds_barrier();
+        IGSTAMP(it, 6);
     }
         {
-            // ---- epilogue of unit k through the buffer that was just read
             const Unit u = unit_of(k);
-            bf16_t* buf = lds + ((it - 1) & 1) * BUF3;
-            float* o_lds = reinterpret_cast<float*>(buf);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o_lds[((4 * wave + r) * T2 + 4 * q + i) * OSTR + 16 * j + m16] = acc[r][j][i];
-            lds_barrier();
-            const int which = u.co0 >= p.n_dst0;
-            const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? u.co0 - p.n_dst0 : u.co0;
-            float* dst = p.dst[which];
-            const int e4 = tid & 15;
-            constexpr int COT = 64, PPP = 16;
-            const int prow = tid >> 4;
-            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE == 0 && p.bias) bias = *reinterpret_cast<const float4*>(p.bias + u.co0 + 4 * e4);
-            BN_EPI_DECL
-#pragma unroll 4
-            for (int v = 0; v < 16; ++v) {
-                const int px = (tid >> 4) + 16 * v, ly = px >> 4, lx = px & 15;
-                const int y = u.y0 + ly, x = u.x0 + lx;
-                if (y >= p.H || x >= p.W) continue;
-                float4 val = *reinterpret_cast<const float4*>(o_lds + px * OSTR + 4 * e4);
-                const size_t o = (((size_t)u.b * p.H + y) * p.W + x) * cw + cl + 4 * e4;
-                if (MODE == 0) {
-                    val.x += bias.x; val.y += bias.y; val.z += bias.z; val.w += bias.w;
-                    if (p.alpha >= 0.f) {
-                        val.x = val.x > 0.f ? val.x : p.alpha * val.x; val.y = val.y > 0.f ? val.y : p.alpha * val.y;
-                        val.z = val.z > 0.f ? val.z : p.alpha * val.z; val.w = val.w > 0.f ? val.w : p.alpha * val.w;
-                    }
-                } else {
-                    if (p.acc[which]) {
-                        const float4 t = *reinterpret_cast<const float4*>(dst + o);
-                        val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w;
-                    }
-                    if (p.mask[which]) {
-                        const float4 mk = *reinterpret_cast<const float4*>(p.mask[which] + o);
-                        val.x *= mk.x > 0.f ? 1.0f : p.alpha; val.y *= mk.y > 0.f ? 1.0f : p.alpha;
-                        val.z *= mk.z > 0.f ? 1.0f : p.alpha; val.w *= mk.w > 0.f ? 1.0f : p.alpha;
-                    }
-                }
-                *reinterpret_cast<float4*>(dst + o) = val;
-                BN_EPI_ACC
-            }
-            BN_EPI_TAIL
-            lds_barrier();          // the next item's staging writes land in this buffer
+            ig::conv3_epilogue<4, MODE>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
+            IGSTAMP(it - 1, 7);
         }
     }
 }
@@ -2357,3 +2355,10 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
 }
 
 }  // namespace dnnca
+
+#ifdef DNNCA_TUNING
+extern "C" int dnnca_debug_ig_stamps(unsigned long long* out, int n) {
+    if (n > 64 * 8) n = 64 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dnnca::igb::g_ig_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -365,7 +365,11 @@ def test_rccl_one_rank_rehearsal(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_one_rank.py')], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert max(out['diff'].values()) <= max(1e-5, 4 * max(out['noise'].values())), out
+    # float atomics make the weight gradients differ run to run in the last bits; three Adam steps (update ~ g / |g|)
+    # amplify that to ~1e-4 of the weights, so the bound on the weights is the larger of a fixed 1e-3 and the noise sample
+    tol = dict(params=1e-3, state=1e-5, grads=1e-5)
+    for key, d in out['diff'].items():
+        assert d <= max(tol[key], 4 * out['noise'][key]), out
     np.testing.assert_allclose(out['losses_plain'], out['losses_rccl'], rtol=1e-6)
     assert out['red'] == [1.5, -2.0]
 
