@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from dnncancerannotator_amd import device as dev                      # noqa: E402
+from dnncancerannotator_amd import distributed                        # noqa: E402
 from dnncancerannotator_amd.synthetic import synthetic_batch         # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec; 6.29 TB/s measured float4 copy)
@@ -38,34 +39,6 @@ WORKLOADS = {
     'mulmo_unet': dict(arch='mulmo', C=3, batch=8, dtype='f32', name='configs/mulmo_unet.yaml',
                        opts=dict(n_filters_first=16, n_downsample=4, rate=2, kernel_size=3, conv_stride=1, bn=True, padding='same')),
 }
-
-
-def rendezvous(rank, world):
-    """RCCL unique id: rank 0 creates it and publishes it in a file named after the launcher (parent) pid."""
-    if world == 1:
-        return None
-    key = '%s_%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
-    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'dnnca_rdzv_%s.id' % key)
-    if rank == 0:
-        uid = dev.DeviceModel.comm_unique_id()
-        tmp = path + '.tmp%d' % os.getpid()
-        with open(tmp, 'wb') as f:
-            f.write(uid)
-        os.replace(tmp, path)
-        return uid
-    t0 = time.time()
-    while True:
-        try:
-            if os.path.getmtime(path) > t0 - 600:
-                with open(path, 'rb') as f:
-                    uid = f.read()
-                if len(uid) == 128:
-                    return uid
-        except OSError:
-            pass
-        if time.time() - t0 > 300:
-            raise RuntimeError('timed out waiting for the RCCL unique id at %s' % path)
-        time.sleep(0.05)
 
 
 def cpu_baseline(sample_steps=6):
@@ -101,9 +74,8 @@ def main():
     ap.add_argument('--workload', default='unet', choices=sorted(WORKLOADS), help='default: the metric\'s configuration (unet)')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
+    ctx = distributed.context()          # RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run (one process per GPU)
+    rank, local_rank, world = ctx.rank, ctx.local_rank, ctx.world
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
@@ -113,7 +85,7 @@ def main():
     C, BATCH_PER_GPU = wl['C'], wl['batch']
     model = dev.DeviceModel(wl['arch'], C, H, W, BATCH_PER_GPU, force_generic=args.generic, dtype=wl['dtype'], **wl['opts'])
     model.init_glorot(seed=2)          # same weights on every rank (random-init weights of the named architecture)
-    uid = rendezvous(rank, world)
+    uid = distributed.exchange_unique_id(ctx, dev.DeviceModel)     # 128-byte RCCL id through a file keyed by the launcher's pid
     model.comm_init(rank, world, uid)
 
     # rank-local shard of the global batch, resident in HBM before the timed region
@@ -196,12 +168,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == 'unet':
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1 and rank == 0:
-        try:
-            key = '%s_%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
-            os.remove(os.path.join(os.environ.get('TMPDIR', '/tmp'), 'dnnca_rdzv_%s.id' % key))
-        except OSError:
-            pass
+    distributed.cleanup(ctx)
     model.close()
 
 

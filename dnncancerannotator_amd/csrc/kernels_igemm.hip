@@ -589,19 +589,27 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
     }
     wg_u32x4 ar[AU], br[BU];
     struct Stage { int b, y0, x0, co0, cc, cs, c0; unsigned oob; __amdgpu_buffer_rsrc_t rs; };
-    auto stage_of = [&](int item) {
-        const int valid = item < nitems;
-        item = valid ? item : 0;
-        const int k = d_chunks.div(item);
-        const Unit u = unit_of(k);
+    // the items are staged in order: next_stage() describes the next one (the unit decode runs only when the unit changes;
+    // recomputing it per item cost 8 % of an item on the one wave a SIMD has)
+    int sg_k = 0, sg_cc = 0;
+    unsigned sg_oob = 0u;
+    Unit sg_u = unit_of(0);
+    auto next_stage = [&]() {
         Stage st;
-        st.b = u.b; st.y0 = u.y0; st.x0 = u.x0; st.co0 = u.co0;
-        st.cc = (item - k * nchunks) * CK;
+        st.b = sg_u.b; st.y0 = sg_u.y0; st.x0 = sg_u.x0; st.co0 = sg_u.co0;
+        st.cc = sg_cc;
         const bool second = st.cc >= p.c_src0;
         st.cs = second ? p.c_src1 : p.c_src0;
         st.c0 = second ? st.cc - p.c_src0 : st.cc;
-        st.oob = valid ? 0u : WG_OOB;
+        st.oob = sg_oob;                    // past the last item: every offset out of range
         st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.src[1] : p.src[0]), 0, second ? nbytes1 : nbytes0, WG_FLAGS);
+        sg_cc += CK;
+        if (sg_cc >= kin) {
+            sg_cc = 0;
+            ++sg_k;
+            if (sg_k < my_units) sg_u = unit_of(sg_k);
+            else sg_oob = WG_OOB;
+        }
         return st;
     };
     auto issue_a = [&](const Stage& st, int v) {
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
 
     f32x4 acc[4][NN];
     {
-        const Stage s0 = stage_of(0);
+        const Stage s0 = next_stage();
 #pragma unroll
         for (int v = 0; v < AU; ++v) issue_a(s0, v);
 #pragma unroll
@@ -636,7 +644,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
         for (int v = 0; v < AU; ++v) commit_a(lds, v);
 #pragma unroll
         for (int v = 0; v < BU; ++v) commit_b(lds, v);
-        const Stage s1 = stage_of(1);
+        const Stage s1 = next_stage();
 #pragma unroll
         for (int v = 0; v < AU; ++v) issue_a(s1, v);
 #pragma unroll
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* buf = lds + (it & 1) * BUF;
         float* other = lds + ((it & 1) ^ 1) * BUF;
-        const Stage nx = stage_of(it + 2);
+        const Stage nx = next_stage();           // item it + 2
         const float* a_lds = buf + ((4 * wave) * (F3T + 2) + m16) * F3AS + q;
         const float* b_lds = buf + ABUF + q * BS + m16;
         // step s = (dx = s / 4, K-step k4 = s % 4): 6 A words (rows 0..5) + 3 x NN B words (dy = 0..2)
@@ -1347,20 +1355,27 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     u32x4 br[BU];
     // item being staged (uniform per block)
     struct Stage { int b, y0, x0, co0, cc, cs, c0; unsigned oob; __amdgpu_buffer_rsrc_t rs; };
-    auto stage_of = [&](int item) {            // items past the end stage nothing: every offset is out of range
-        const int valid = item < nitems;
-        item = valid ? item : 0;
-        const int k = d_chunks.div(item);
-        const Unit u = unit_of(k);
+    // the items are staged in order: next_stage() describes the next one (the unit decode runs only when the unit changes;
+    // recomputing it per item cost 8 % of an item on the one wave a SIMD has)
+    int sg_k = 0, sg_cc = 0;
+    unsigned sg_oob = 0u;
+    Unit sg_u = unit_of(0);
+    auto next_stage = [&]() {
         Stage st;
-        st.b = u.b; st.y0 = u.y0; st.x0 = u.x0; st.co0 = u.co0;
-        st.cc = (item - k * nchunks) * CK;
+        st.b = sg_u.b; st.y0 = sg_u.y0; st.x0 = sg_u.x0; st.co0 = sg_u.co0;
+        st.cc = sg_cc;
         const bool second = st.cc >= p.c_src0;
         st.cs = second ? p.c_src1 : p.c_src0;
         st.c0 = second ? st.cc - p.c_src0 : st.cc;
-        st.oob = valid ? 0u : OOB;          // OR-ed into every offset
-        // descriptor of this chunk's source built from scalar selects (no branch inside the MFMA stream)
+        st.oob = sg_oob;                    // past the last item: every offset out of range
         st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.src[1] : p.src[0]), 0, second ? nbytes1 : nbytes0, BUF_FLAGS);
+        sg_cc += CK;
+        if (sg_cc >= kin) {
+            sg_cc = 0;
+            ++sg_k;
+            if (sg_k < my_units) sg_u = unit_of(sg_k);
+            else sg_oob = OOB;
+        }
         return st;
     };
     auto issue_a = [&](const Stage& st, int v) {
@@ -1393,7 +1408,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     f32x4 acc[4][4];
     // ---- prologue: item 0 into buffer 0, item 1 into registers
     {
-        const Stage s0 = stage_of(0);
+        const Stage s0 = next_stage();
 #pragma unroll
         for (int v = 0; v < AU; ++v) issue_a(s0, v);
 #pragma unroll
@@ -1402,13 +1417,11 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         for (int v = 0; v < AU; ++v) commit_a(lds, v);
 #pragma unroll
         for (int v = 0; v < BU; ++v) commit_b(lds, v);
-        if (nitems > 1) {
-            const Stage s1 = stage_of(1);
+        const Stage s1 = next_stage();
 #pragma unroll
-            for (int v = 0; v < AU; ++v) issue_a(s1, v);
+        for (int v = 0; v < AU; ++v) issue_a(s1, v);
 #pragma unroll
-            for (int v = 0; v < BU; ++v) issue_b(s1, v);
-        }
+        for (int v = 0; v < BU; ++v) issue_b(s1, v);
     }
     lds_barrier();
     // units outside, K chunks inside: the accumulators are plainly zeroed per unit (a conditional reset inside one flat
@@ -1425,7 +1438,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         bf16_t* buf = lds + (it & 1) * BUF3;
         bf16_t* other = lds + ((it & 1) ^ 1) * BUF3;
         IGSTAMP(it, 0);
-        const Stage nx = stage_of(it + 2);
+        const Stage nx = next_stage();           // item it + 2
         IGSTAMP(it, 1);
         const bf16_t* a_lds = buf + ((4 * wave) * (T2 + 2) + m16) * RS + 8 * q;
         const bf16_t* b_lds = buf + PATCH2 * RS + m16 * RS + 8 * q;

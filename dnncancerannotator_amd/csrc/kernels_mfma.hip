@@ -935,7 +935,7 @@ int fast_prepare(Model* m) {
     const int nprep = (pl.bmat_n + 255) / 256;
     StepInit z{};
     int nz = 0;
-    if (m->defer_head && m->prof_mode == 0 && !m->dry) {      // dnnca_train_step: a backward pass follows this forward pass
+    if (m->defer_head && m->merged_launches() && !m->dry) {      // dnnca_train_step: a backward pass follows this forward pass
         z.scalars = m->scalars;
         z.a = reinterpret_cast<float4*>(m->g);
         z.na4 = (unsigned)((m->nT + 8 + 3) / 4);                // both buffers are allocated with >= 16 bytes of slack

@@ -367,7 +367,7 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
 #define HEAD_CASE(c, px)                                                                                               \
     if (C == c) {                                                                                                      \
         LAUNCH(m, "head_train_" #c, bytes, 30.0 * npix, hipLaunchKernelGGL((k_head_train<c, px>), dim3(blocks), dim3(256), 0, m->stream, a)); \
-        if (m->head_defer_ok && m->prof_mode == 0) {       /* reduced by the launch that ends the backward pass (k_pg_fold) */ \
+        if (m->head_defer_ok && m->merged_launches()) {       /* reduced by the launch that ends the backward pass (k_pg_fold) */ \
             m->head_pending.partials = m->head_partials; m->head_pending.nblocks = blocks; m->head_pending.C = c;       \
             m->head_pending.dw = a.dw; m->head_pending.dbias = a.dbias;                                                \
             return true;                                                                                               \

@@ -585,7 +585,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                    g_l2(stream, (size_t)pi.size, p + pi.offset, g + pi.offset, desc.l2, scalars));
         }
     }
-    if (backward && !comm && !dry && prof_mode == 0) {
+    if (backward && !comm && !dry && merged_launches()) {
         // optimizer_step() follows every backward pass: its Adam launch also writes the step outputs (one launch fewer)
         fin_pending.on = true;
         fin_pending.cfg = cfg;
