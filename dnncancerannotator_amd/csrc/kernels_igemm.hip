@@ -57,12 +57,12 @@ struct ConvArgs {
 // instruction writes four 64-byte channel runs.  (The earlier version transposed the tile through LDS to store 256-byte rows:
 // 64 LDS writes + 16 LDS reads per lane and up to five barriers cost as much as 1.7 K-chunks of MFMAs per tile.)
 //   MODE 0: + bias, activation; the BatchNorm behind the conv takes its batch statistics from here (ConvArgs::bn_part): per-lane
-//           sums over the lane's 16 pixels, the four q groups folded by two wave shuffles, the four waves through `red`
-//           ([4][2 COT] floats of LDS) -- one barrier;
+//           sums over the lane's 16 pixels, the four q groups folded by two wave shuffles, the NW waves through `red`
+//           ([NW][2 COT] floats of LDS) -- one barrier;
 //   MODE 1: accumulate into dst and multiply by act'(mask tensor) as requested.
 // (The backward sums of a BatchNorm were tried in the data-gradient epilogue too: the extra read of the normalised input
 // there cost more than the reduction pass it replaced -- 2.1 -> 3.2 ms of dgrad against 0.7 ms saved.)
-template <int NN, int MODE>
+template <int NN, int MODE, int NW = 4>
 __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0, int tile,
                                                float* red) {
     constexpr int COT = 16 * NN;
@@ -145,7 +145,9 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
         }
         lds_barrier();
         if (tid < 2 * COT) {
-            const float a = (red[tid] + red[2 * COT + tid]) + (red[4 * COT + tid] + red[6 * COT + tid]);
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += red[w * (2 * COT) + tid];
             const int half = tid >= COT, c = half ? tid - COT : tid;
             p.bn_part[(size_t)tile * (2 * cw) + half * cw + cl + c] = a;
         }
@@ -1296,11 +1298,21 @@ constexpr int BUF3 = (PATCH2 + 9 * 64) * RS + 64;   // bf16 elements per LDS buf
 constexpr unsigned BUF_FLAGS = 0x00020000u;         // raw buffer descriptor word 3 (gfx9 family)
 constexpr unsigned OOB = 0x80000000u;               // beyond every tensor here: the buffer load returns zeros
 
-// A16: the sources are stored as bf16 (View::h): 16-byte loads of 8 channels go to LDS as they are
-template <int MODE, bool A16>
-__global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* __restrict__ w16) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * BUF3];
-    __shared__ float bn_red[4 * 2 * 64];        // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
+// A16: the sources are stored as bf16 (View::h): 16-byte loads of 8 channels go to LDS as they are.
+// NW: waves per block.  4: 16 x 16-pixel tiles, one wave per SIMD.  8: 32 x 16-pixel tiles, two waves per SIMD (256 registers
+// each) -- a single wave cannot issue v_mfma_f32_16x16x32_bf16 back to back (1.7 of 2.46 PFLOP/s, mfma_bf16_rate.hip), the
+// second wave fills those slots and the first one's waits, and the weight slab and the barrier serve twice the MFMAs; the
+// two 76 KB buffers only fit with unpadded 64-byte rows (a fragment read then covers one contiguous KB: conflict-free too).
+template <int MODE, bool A16, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_igb_conv3(ConvArgs p, const bf16_t* __restrict__ w16) {
+    constexpr int NT = 64 * NW, TR = 4 * NW;                  // threads, tile rows
+    constexpr int PATCHX = (TR + 2) * (T2 + 2);               // staged pixels
+    constexpr int RSX = NW == 8 ? 32 : RS;                    // bf16 per LDS row
+    constexpr int BOFF = PATCHX * RSX, DUMP = (PATCHX + 9 * 64) * RSX, BUFX = DUMP + 64;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NW == 8 || BUFX == BUF3, "layout of the 4-wave kernel");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * BUFX];
+    __shared__ float bn_red[NW * 2 * 64];       // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4;
     const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
@@ -1333,23 +1345,24 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x;
         u.b = d_ty.div(trow);
         const int by = trow - u.b * p.tiles_y;
-        u.x0 = bx * T2; u.y0 = by * T2; u.co0 = cot * 64; u.tile = tile;
+        u.x0 = bx * T2; u.y0 = by * TR; u.co0 = cot * 64; u.tile = tile;
         return u;
     };
 
     // ---- staging geometry of this thread: A element v = patch pixel tid / TPP + PPV v, channels CPT (tid % TPP)..
     //      (f32 sources: 8 threads x 4 channels per pixel; bf16 sources: 4 threads x 8 channels);
     //      B element v = tap v, output channel tid >> 2, K part tid & 3
-    constexpr int TPP = A16 ? 4 : 8, PPV = 256 / TPP, CPT = CK / TPP;
-    constexpr int AU = (PATCH2 * TPP + 255) / 256, BU = 9;
-    const int c4 = tid & (TPP - 1), bn = tid >> 2, bpart = tid & 3;
+    constexpr int TPP = A16 ? 4 : 8, PPV = NT / TPP, CPT = CK / TPP;
+    constexpr int AU = (PATCHX * TPP + NT - 1) / NT, BU = (9 * 256 + NT - 1) / NT;      // B: 9 taps x 64 rows x 4 16-byte parts
+    static_assert(AU <= 16 && BU <= 9, "staging slices of the tap loop");
+    const int c4 = tid & (TPP - 1);
     int a_ly[AU], a_lx[AU];
 #pragma unroll
     for (int v = 0; v < AU; ++v) {
         const int px = tid / TPP + PPV * v;
         a_ly[v] = px / (T2 + 2);
         a_lx[v] = px - a_ly[v] * (T2 + 2);
-        if (px >= PATCH2) a_ly[v] = -4096;          // never inside an image
+        if (px >= PATCHX) a_ly[v] = -4096;          // never inside an image
     }
     u32x4 ar[AU];
     u32x4 br[BU];
@@ -1384,14 +1397,15 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         const unsigned off = (ok ? (unsigned)(((((st.b * p.H + iy) * p.W + ix) * st.cs) + st.c0 + CPT * c4) * ESZ) : OOB) | st.oob;
         ar[v] = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
     };
-    auto issue_b = [&](const Stage& st, int v) {
-        const unsigned off = (unsigned)((((v * nout + st.co0 + bn) * kin) + st.cc + 8 * bpart) * 2) | st.oob;
+    auto issue_b = [&](const Stage& st, int v) {          // piece i = tid + NT v: tap i / 256, output channel (i / 4) % 64, K part i % 4
+        const int i = tid + NT * v, tap = i >> 8, bn = (i >> 2) & 63, bpart = i & 3;
+        const unsigned off = (i < 9 * 256 ? (unsigned)((((tap * nout + st.co0 + bn) * kin) + st.cc + 8 * bpart) * 2) : OOB) | st.oob;
         br[v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0);
     };
     auto commit_a = [&](bf16_t* buf, int v) {
         const int px = tid / TPP + PPV * v;
         // branch-free: lanes past the patch (last element only) write into the buffer's dump row
-        bf16_t* dst = buf + (px < PATCH2 ? px * RS : (PATCH2 + 9 * 64) * RS) + CPT * c4;
+        bf16_t* dst = buf + (px < PATCHX ? px * RSX : DUMP) + CPT * c4;
         if constexpr (A16) {
             *reinterpret_cast<u32x4*>(dst) = ar[v];
         } else {
@@ -1402,7 +1416,8 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
         }
     };
     auto commit_b = [&](bf16_t* buf, int v) {
-        *reinterpret_cast<u32x4*>(buf + PATCH2 * RS + (64 * v + bn) * RS + 8 * bpart) = br[v];
+        const int i = tid + NT * v, bpart = i & 3;
+        *reinterpret_cast<u32x4*>(buf + (i < 9 * 256 ? BOFF + (i >> 2) * RSX : DUMP) + 8 * bpart) = br[v];
     };
 
     f32x4 acc[4][4];
@@ -1435,18 +1450,21 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
             for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
-        bf16_t* buf = lds + (it & 1) * BUF3;
-        bf16_t* other = lds + ((it & 1) ^ 1) * BUF3;
+        bf16_t* buf = lds + (it & 1) * BUFX;
+        bf16_t* other = lds + ((it & 1) ^ 1) * BUFX;
         IGSTAMP(it, 0);
         const Stage nx = next_stage();           // item it + 2
         IGSTAMP(it, 1);
-        const bf16_t* a_lds = buf + ((4 * wave) * (T2 + 2) + m16) * RS + 8 * q;
-        const bf16_t* b_lds = buf + PATCH2 * RS + m16 * RS + 8 * q;
-        bf16x8 fa[2][6], fb[2][4];
+        const bf16_t* a_lds = buf + ((4 * wave) * (T2 + 2) + m16) * RSX + 8 * q;
+        const bf16_t* b_lds = buf + BOFF + m16 * RSX + 8 * q;
+        // B fragments: double-buffered with one wave per SIMD; with two the other wave covers the read latency and the 16
+        // registers are what keeps the kernel inside its 256 (the double-buffered version spilled 2-19 of them)
+        constexpr int FB = NW == 8 ? 1 : 2;
+        bf16x8 fa[2][6], fb[FB][4];
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) fa[0][rr] = *reinterpret_cast<const bf16x8*>(a_lds + (rr * (T2 + 2)) * RS);
+        for (int rr = 0; rr < 6; ++rr) fa[0][rr] = *reinterpret_cast<const bf16x8*>(a_lds + (rr * (T2 + 2)) * RSX);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(b_lds + (16 * j) * RS);
+        for (int j = 0; j < 4; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(b_lds + (16 * j) * RSX);
         IGSTAMP(it, 2);
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
@@ -1459,10 +1477,12 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
                 const int g1 = (s + 1) / 3, dy1 = (s + 1) % 3;
                 if (dy1 == 0) {
 #pragma unroll
-                    for (int rr = 0; rr < 6; ++rr) fa[g1 & 1][rr] = *reinterpret_cast<const bf16x8*>(a_lds + (rr * (T2 + 2) + g1) * RS);
+                    for (int rr = 0; rr < 6; ++rr) fa[g1 & 1][rr] = *reinterpret_cast<const bf16x8*>(a_lds + (rr * (T2 + 2) + g1) * RSX);
                 }
+                if (FB == 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(b_lds + ((dy1 * 3 + g1) * 64 + 16 * j) * RS);
+                    for (int j = 0; j < 4; ++j) fb[(s + 1) & (FB - 1)][j] = *reinterpret_cast<const bf16x8*>(b_lds + ((dy1 * 3 + g1) * 64 + 16 * j) * RSX);
+                }
             }
             if (s >= 1) {                               // staging slice s-1: elements {s-1, s-1+8}
                 const int v0 = s - 1, v1 = s + 7;
@@ -1470,15 +1490,19 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
                 // commit writes stale registers into the buffer nobody reads again and the loads are out of range
                 if (v0 < AU) { commit_a(other, v0); issue_a(nx, v0); }
                 if (v1 < AU) { commit_a(other, v1); issue_a(nx, v1); }
-                commit_b(other, v0);
-                issue_b(nx, v0);
+                if (v0 < BU) { commit_b(other, v0); issue_b(nx, v0); }
                 if (v1 < BU) { commit_b(other, v1); issue_b(nx, v1); }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][r + dy], fb[s & 1][j], acc[r][j], 0, 0, 0);
+                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][r + dy], fb[s & (FB - 1)][j], acc[r][j], 0, 0, 0);
+            if (FB == 1 && s + 1 < 9) {
+                const int g1 = (s + 1) / 3, dy1 = (s + 1) % 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(b_lds + ((dy1 * 3 + g1) * 64 + 16 * j) * RSX);
+            }
         }
         IGSTAMP(it, 5);
         lds_barrier();
@@ -1486,7 +1510,7 @@ __global__ __launch_bounds__(256, 1) void k_igb_conv3(ConvArgs p, const bf16_t* 
     }
         {
             const Unit u = unit_of(k);
-            ig::conv3_epilogue<4, MODE>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
+            ig::conv3_epilogue<4, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
             IGSTAMP(it - 1, 7);
         }
     }
@@ -2076,7 +2100,14 @@ static bool conv3_path(const ig::ConvArgs& a, int cout, bool bf16) {
     if (bf16) return fits && cout % 64 == 0 && a.c_src0 % 32 == 0 && a.c_src1 % 32 == 0 && a.n_dst0 % 64 == 0;
     return fits && !getenv("DNNCA_IGCONV1");
 }
-static int conv3_rows(const ig::ConvArgs& a) { return ((a.W + 15) / 16) * ((a.H + 15) / 16) * a.B; }     // 16 x 16 pixel tiles
+// waves per block of igb::k_igb_conv3: 8 (32 x 16-pixel tiles, two waves per SIMD) once that still gives every CU a unit
+static int igb_waves(const ig::ConvArgs& a, int cout) {
+    static const int forced = getenv("DNNCA_IGB_NW") ? atoi(getenv("DNNCA_IGB_NW")) : 0;      // tuning aid: 4 or 8
+    if (forced == 4 || forced == 8) return forced;
+    const long units8 = (long)((a.W + 15) / 16) * ((a.H + 31) / 32) * a.B * (cout / 64);
+    return units8 >= 256 ? 8 : 4;
+}
+static int conv3_rows(const ig::ConvArgs& a, int tile_rows) { return ((a.W + 15) / 16) * ((a.H + tile_rows - 1) / tile_rows) * a.B; }
 
 template <int MODE>
 static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* name, double bytes, double flops) {
@@ -2110,14 +2141,15 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
     const int nn = pick_nn(cout);
     if (conv3_path(a, cout, true)) {
         ig::ConvArgs a2 = a;
+        const int nw = igb_waves(a, cout);
         a2.tiles_x = (a.W + igb::T2 - 1) / igb::T2;
-        a2.tiles_y = (a.H + igb::T2 - 1) / igb::T2;
+        a2.tiles_y = (a.H + 4 * nw - 1) / (4 * nw);
         const unsigned nblocks = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / 64));
         const unsigned g = nblocks < 256u ? nblocks : 256u;
-        if (a.src_half)
-            LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE, true>), dim3(g), dim3(256), 0, m->stream, a2, w16));
-        else
-            LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE, false>), dim3(g), dim3(256), 0, m->stream, a2, w16));
+#define IGB3(A16v, NWv) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE, A16v, NWv>), dim3(g), dim3(64 * NWv), 0, m->stream, a2, w16))
+        if (a.src_half) { if (nw == 8) IGB3(true, 8); else IGB3(true, 4); }
+        else { if (nw == 8) IGB3(false, 8); else IGB3(false, 4); }
+#undef IGB3
         return;
     }
     dim3 grid(a.tiles_x * a.tiles_y * a.B, cout / (16 * nn));
@@ -2140,7 +2172,7 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
     a.src_half = o.inA.d.h;          // ig_plan_half keeps both sources of a conv in the same format
     if (bn_next && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
         // the BatchNorm behind this conv takes its batch statistics from the conv's epilogue
-        const int rows = conv3_rows(a);
+        const int rows = conv3_rows(a, use_bf16(m, o) ? 4 * igb_waves(a, o.out.d.C) : 16);     // one partial row per pixel tile
         void* part = nullptr;
         if (m->dry) {
             bn_next->fused_stats_rows = rows;          // the dry run lists the launches of the real one
