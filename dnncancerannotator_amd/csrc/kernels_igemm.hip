@@ -535,13 +535,17 @@ __global__ __launch_bounds__(256) void k_wg_fold(float* __restrict__ slabs, int 
 constexpr int F3T = 16, F3PATCH = (F3T + 2) * (F3T + 2);       // tile edge, staged patch pixels
 constexpr int F3AS = CK + 4;                                    // A row stride (floats)
 
-template <int NN, int MODE>
-__global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
+// NW = 8 (NN <= 2: the two buffers of a 32-row tile fit): 32 x 16-pixel tiles, two waves per SIMD -- the second wave covers the
+// first one's LDS waits, epilogue and barrier, and the weight slab serves twice the MFMAs (see igb::k_igb_conv3).
+template <int NN, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
+    constexpr int NT = 64 * NW, TR = 4 * NW, PATCHX = (TR + 2) * (F3T + 2);
     constexpr int COT = 16 * NN, BS = COT + 16;                 // B row stride (floats): 16 (mod 32) banks
-    constexpr int ABUF = F3PATCH * F3AS, BBUF = 9 * CK * BS;
+    constexpr int ABUF = PATCHX * F3AS, BBUF = 9 * CK * BS;
     constexpr int BUF = ABUF + BBUF + 16;                       // floats per LDS buffer
+    static_assert(NW == 4 || (NW == 8 && NN <= 2), "eight waves: 16- and 32-channel tiles only (LDS)");
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
-    __shared__ float bn_red[4 * 2 * COT];       // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
+    __shared__ float bn_red[NW * 2 * COT];      // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4;
     const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
@@ -573,21 +577,22 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
         const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x;
         u.b = d_ty.div(trow);
         const int by = trow - u.b * p.tiles_y;
-        u.x0 = bx * F3T; u.y0 = by * F3T; u.co0 = cot * COT; u.tile = tile;
+        u.x0 = bx * F3T; u.y0 = by * TR; u.co0 = cot * COT; u.tile = tile;
         return u;
     };
 
-    // staging geometry: A element v = patch pixel (tid >> 2) + 64 v, float4 tid & 3; B element v = slab row
-    // (tid + 256 v) / (4 NN) (= tap * 16 + k), float4 (tid + 256 v) % (4 NN)
-    constexpr int AU = (F3PATCH * 4 + 255) / 256, BU = (9 * CK * 4 * NN + 255) / 256;
+    // staging geometry: A element v = patch pixel (tid >> 2) + (NT / 4) v, float4 tid & 3; B element v = slab row
+    // (tid + NT v) / (4 NN) (= tap * 16 + k), float4 (tid + NT v) % (4 NN)
+    constexpr int AU = (PATCHX * 4 + NT - 1) / NT, BU = (9 * CK * 4 * NN + NT - 1) / NT;
+    static_assert(AU <= 9 && BU <= 9, "nine staging slices per item");
     const int c4 = tid & 3;
     int a_ly[AU], a_lx[AU];
 #pragma unroll
     for (int v = 0; v < AU; ++v) {
-        const int px = (tid >> 2) + 64 * v;
+        const int px = (tid >> 2) + (NT / 4) * v;
         a_ly[v] = px / (F3T + 2);
         a_lx[v] = px - a_ly[v] * (F3T + 2);
-        if (px >= F3PATCH) a_ly[v] = -4096;
+        if (px >= PATCHX) a_ly[v] = -4096;
     }
     wg_u32x4 ar[AU], br[BU];
     struct Stage { int b, y0, x0, co0, cc, cs, c0; unsigned oob; __amdgpu_buffer_rsrc_t rs; };
@@ -621,17 +626,17 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
         ar[v] = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
     };
     auto issue_b = [&](const Stage& st, int v) {
-        const int i = tid + 256 * v, n4 = i % (4 * NN), r = i / (4 * NN);
+        const int i = tid + NT * v, n4 = i % (4 * NN), r = i / (4 * NN);
         const bool ok = r < 9 * CK;
         const unsigned off = (ok ? (unsigned)(((((r >> 4) * kin + st.cc + (r & 15)) * nout) + st.co0 + 4 * n4) * 4) : WG_OOB) | st.oob;
         br[v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0);
     };
     auto commit_a = [&](float* buf, int v) {
-        const int px = (tid >> 2) + 64 * v;
-        *reinterpret_cast<wg_u32x4*>(buf + (px < F3PATCH ? px * F3AS : ABUF + BBUF) + 4 * c4) = ar[v];     // idle lanes: dump row
+        const int px = (tid >> 2) + (NT / 4) * v;
+        *reinterpret_cast<wg_u32x4*>(buf + (px < PATCHX ? px * F3AS : ABUF + BBUF) + 4 * c4) = ar[v];     // idle lanes: dump row
     };
     auto commit_b = [&](float* buf, int v) {
-        const int i = tid + 256 * v, n4 = i % (4 * NN), r = i / (4 * NN);
+        const int i = tid + NT * v, n4 = i % (4 * NN), r = i / (4 * NN);
         *reinterpret_cast<wg_u32x4*>(buf + (r < 9 * CK ? ABUF + r * BS + 4 * n4 : ABUF + BBUF + 4 * (n4 & 3))) = br[v];
     };
 
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_conv3(ConvArgs p) {
     }
         {
             const Unit u = unit_of(k);
-            conv3_epilogue<NN, MODE>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
+            conv3_epilogue<NN, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
         }
     }
 }
@@ -2107,24 +2112,36 @@ static int igb_waves(const ig::ConvArgs& a, int cout) {
     const long units8 = (long)((a.W + 15) / 16) * ((a.H + 31) / 32) * a.B * (cout / 64);
     return units8 >= 256 ? 8 : 4;
 }
+// waves per block of ig::k_ig_conv3 (f32): 8 for 16- / 32-channel tiles (the channel tile launch_ig picks) with enough units
+static int ig_nn3(const ig::ConvArgs& a) {
+    const int d1 = a.n_dst1 ? a.n_dst1 : 64;
+    return (a.n_dst0 % 64 == 0 && d1 % 64 == 0) ? 4 : ((a.n_dst0 % 32 == 0 && d1 % 32 == 0) ? 2 : 1);
+}
+static int ig_waves(const ig::ConvArgs& a, int cout) {
+    static const int forced = getenv("DNNCA_IG_NW") ? atoi(getenv("DNNCA_IG_NW")) : 0;        // tuning aid: 4 or 8
+    const int nn3 = ig_nn3(a);
+    if (nn3 == 4 || forced == 4) return 4;
+    const long units8 = (long)((a.W + 15) / 16) * ((a.H + 31) / 32) * a.B * (cout / (16 * nn3));
+    return (forced == 8 || units8 >= 256) ? 8 : 4;
+}
 static int conv3_rows(const ig::ConvArgs& a, int tile_rows) { return ((a.W + 15) / 16) * ((a.H + tile_rows - 1) / tile_rows) * a.B; }
 
 template <int MODE>
 static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* name, double bytes, double flops) {
     {   // pipelined persistent kernel: channel tile 16 nn3 must divide both destinations; 32-bit byte offsets
-        const int d1 = a.n_dst1 ? a.n_dst1 : 64;
-        const int nn3 = (a.n_dst0 % 64 == 0 && d1 % 64 == 0) ? 4 : ((a.n_dst0 % 32 == 0 && d1 % 32 == 0) ? 2 : 1);
-        const int cmax = a.c_src0 > a.c_src1 ? a.c_src0 : a.c_src1;
-        (void)cmax;
+        const int nn3 = ig_nn3(a);
         if (conv3_path(a, cout, false)) {
             ig::ConvArgs a2 = a;
+            const int nw = ig_waves(a, cout);
             a2.tiles_x = (a.W + ig::F3T - 1) / ig::F3T;
-            a2.tiles_y = (a.H + ig::F3T - 1) / ig::F3T;
+            a2.tiles_y = (a.H + 4 * nw - 1) / (4 * nw);
             const unsigned units = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / (16 * nn3)));
             const unsigned g = units < 256u ? units : 256u;
-            if (nn3 == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<4, MODE>), dim3(g), dim3(256), 0, m->stream, a2));
-            else if (nn3 == 2) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<2, MODE>), dim3(g), dim3(256), 0, m->stream, a2));
-            else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<1, MODE>), dim3(g), dim3(256), 0, m->stream, a2));
+            if (nn3 == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<4, MODE, 4>), dim3(g), dim3(256), 0, m->stream, a2));
+            else if (nn3 == 2 && nw == 8) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<2, MODE, 8>), dim3(g), dim3(512), 0, m->stream, a2));
+            else if (nn3 == 2) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<2, MODE, 4>), dim3(g), dim3(256), 0, m->stream, a2));
+            else if (nw == 8) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<1, MODE, 8>), dim3(g), dim3(512), 0, m->stream, a2));
+            else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<1, MODE, 4>), dim3(g), dim3(256), 0, m->stream, a2));
             return;
         }
     }
@@ -2172,7 +2189,7 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
     a.src_half = o.inA.d.h;          // ig_plan_half keeps both sources of a conv in the same format
     if (bn_next && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
         // the BatchNorm behind this conv takes its batch statistics from the conv's epilogue
-        const int rows = conv3_rows(a, use_bf16(m, o) ? 4 * igb_waves(a, o.out.d.C) : 16);     // one partial row per pixel tile
+        const int rows = conv3_rows(a, 4 * (use_bf16(m, o) ? igb_waves(a, o.out.d.C) : ig_waves(a, o.out.d.C)));     // one partial row per pixel tile
         void* part = nullptr;
         if (m->dry) {
             bn_next->fused_stats_rows = rows;          // the dry run lists the launches of the real one
