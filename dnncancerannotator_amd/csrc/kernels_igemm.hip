@@ -1669,6 +1669,117 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
     }
 }
 
+// k_igb_wgrad64 with eight waves per block (two per SIMD) for bf16-stored operands: the same 8 x 16-pixel tiles and 64 x 64
+// channel block, wave & 3 = 16-channel slice of the input channels, wave >> 2 = half of the output channels -- 72 instead of
+// 144 accumulator registers per wave, so two waves fit a SIMD: full-rate MFMA issue (one wave alone reaches 1.7 of 2.46
+// PFLOP/s) and one wave's transposing reads hide behind the other's MFMAs.  Every wave still adds distinct elements to the
+// gradient: the atomic traffic is unchanged.
+__global__ __launch_bounds__(512, 2) void k_igb_wgrad64w(ig::WgArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t ximg[PATCH * WRS];
+    __shared__ __attribute__((aligned(16))) bf16_t gimg[TY * TX * WRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int gq = (lane >> 2) & 3, gp = lane & 3;
+    const int c0 = blockIdx.y * 64, co0 = blockIdx.z * 64 + 32 * wn;
+    const bool do_bias = p.dbias && blockIdx.y == 0 && wm == 0;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+
+    f32x4 acc[9][2], accb[2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int XU = (PATCH * 16 + 511) / 512, GU = TY * TX * 16 / 512;      // 6 and 4 8-byte elements per thread
+    const FastDiv d_tx(p.tiles_x), d_ty(p.tiles_y);
+    bf16x4 xr[XU], gr[GU];
+    const bf16_t* x16 = reinterpret_cast<const bf16_t*>(p.x);
+    const bf16_t* g16 = reinterpret_cast<const bf16_t*>(p.dz);
+    const bf16x4 zero4 = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    auto issue = [&](int tile) {
+        const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x, b = d_ty.div(trow), by = trow - b * p.tiles_y;
+        const int x0 = bx * TX, y0 = by * TY;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 512 * u, px = i >> 4, c4 = i & 15;
+            const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            xr[u] = zero4;
+            if (px < PATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                xr[u] = *reinterpret_cast<const bf16x4*>(x16 + (((size_t)b * p.H + iy) * p.W + ix) * p.cs + c0 + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 512 * u, px = i >> 4, n4 = i & 15;
+            const int ly = px / TX, lx = px - ly * TX;
+            const int iy = y0 + ly, ix = x0 + lx;
+            gr[u] = zero4;
+            if (iy < p.H && ix < p.W)
+                gr[u] = *reinterpret_cast<const bf16x4*>(g16 + (((size_t)b * p.H + iy) * p.W + ix) * p.cout + blockIdx.z * 64 + 4 * n4);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 512 * u, px = i >> 4, c4 = i & 15;
+            if (px < PATCH) *reinterpret_cast<bf16x4*>(ximg + px * WRS + 4 * c4) = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 512 * u, px = i >> 4, n4 = i & 15;
+            *reinterpret_cast<bf16x4*>(gimg + px * WRS + 4 * n4) = gr[u];
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    const int xbase = (4 * q + gq) * WRS + 16 * wm + 4 * gp;
+    const int gbase = (4 * q + gq) * WRS + 32 * wn + 4 * gp;
+#pragma unroll 1
+    for (; tile < ntiles; tile += p.psplit) {
+        lds_barrier();              // the previous tile's fragment reads are complete
+        commit();
+        if (tile + p.psplit < ntiles) issue(tile + p.psplit);
+        lds_barrier();
+#pragma unroll 1
+        for (int s = 0; s < TY / 2; ++s) {
+            bf16x8 bv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bv[j] = tr_frag(gimg + gbase + (2 * s * TX) * WRS + 16 * j, gimg + gbase + ((2 * s + 1) * TX) * WRS + 16 * j);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t % 3;
+                const bf16x8 av = tr_frag(ximg + xbase + ((2 * s + dy) * (TX + 2) + dx) * WRS,
+                                          ximg + xbase + ((2 * s + 1 + dy) * (TX + 2) + dx) * WRS);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[t][j], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bv[j], accb[j], 0, 0, 0);
+            }
+        }
+    }
+    // D[ci = 16 wm + 4q + i][co = 32 wn + 16j + m16]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(p.dw + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
+    if (do_bias && q == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) atomicAdd(p.dbias + co0 + 16 * j + m16, accb[j][0]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bf16 transposed conv
 // Conv2DTranspose(k = s = 2) under dtype bf16: four 1x1 GEMMs (one per output parity) that share their input tile.  All
 // three passes are HBM passes over the 4x larger output tensor; the point of these kernels is to read / write every
@@ -2263,6 +2374,11 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             w.psplit = ps < 1 ? 1 : ps;
             const dim3 g64(w.psplit, w.cs / 64, CO / 64);
             const bool xh = (s == 0 ? o.inA.d.h : o.inB.d.h) != 0, gh = o.out.g.h != 0;
+            static const int narrow = getenv("DNNCA_WGRAD64_NARROW") != nullptr;          // tuning aid
+            if (xh && gh && !narrow) {         // eight waves per block (bf16-stored operands)
+                LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL(igb::k_igb_wgrad64w, g64, dim3(512), 0, m->stream, w));
+                continue;
+            }
 #define WG64(XH, GH) LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad64<XH, GH>), g64, dim3(256), 0, m->stream, w))
             if (xh) { if (gh) WG64(true, true); else WG64(true, false); }
             else { if (gh) WG64(false, true); else WG64(false, false); }
