@@ -60,8 +60,10 @@ struct ConvArgs {
 //           sums over the lane's 16 pixels, the four q groups folded by two wave shuffles, the NW waves through `red`
 //           ([NW][2 COT] floats of LDS) -- one barrier;
 //   MODE 1: accumulate into dst and multiply by act'(mask tensor) as requested.
-// (The backward sums of a BatchNorm were tried in the data-gradient epilogue too: the extra read of the normalised input
-// there cost more than the reduction pass it replaced -- 2.1 -> 3.2 ms of dgrad against 0.7 ms saved.)
+// (The backward sums of a BatchNorm were tried in the data-gradient epilogue too, twice: the extra read of the BatchNorm's
+// input there costs about what the reduction pass it replaces does -- with the LDS-staged epilogue and one wave per SIMD
+// 2.1 -> 3.2 ms of dgrad against 0.7 ms saved; with this epilogue and two waves per SIMD +0.44 ms of dgrad against 0.63 ms on
+// unet_big, and a net loss on mulmo_unet, where the fold of the per-tile partials also grows.)
 template <int NN, int MODE, int NW = 4>
 __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0, int tile,
                                                float* red) {
