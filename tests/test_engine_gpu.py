@@ -250,17 +250,21 @@ def test_unet_big_bf16_contraction_against_oracle(gpu):
     m.close()
 
 
-def test_bf16_storage_of_rounded_tensors_is_transparent(gpu, monkeypatch):
+@pytest.mark.parametrize('arch,C,opts,size', [
+    ('unet', 1, dict(n_filters_first=64, n_downsample=2), 64),
+    ('mulmo', 3, dict(n_filters_first=16, n_downsample=4), 128),       # 16/32-channel levels stay f32, 64/128 go bf16: mixed plan
+])
+def test_bf16_storage_of_rounded_tensors_is_transparent(gpu, monkeypatch, arch, C, opts, size):
     """dtype bf16 keeps the tensors whose every reader rounds to bf16 anyway (BatchNorm outputs feeding the 64-channel conv
     kernels, the conv-output gradients from the BatchNorm backward) as bf16 in HBM (ig_plan_half).  That must not change a
     single bit of the forward pass; gradients may differ by the summation order of the float atomics only."""
-    opts = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', n_filters_first=64, n_downsample=2, bn=True)
-    x, y = O.synthetic_batch(2, 64, 64, 1)
+    opts = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', bn=True, **opts)
+    x, y = O.synthetic_batch(2, size, size, C)
     res = []
     for no_half in (False, True):
         if no_half:
             monkeypatch.setenv('DNNCA_NO_HALF', '1')
-        m = gpu.DeviceModel('unet', 1, 64, 64, 2, dtype='bf16', **opts)
+        m = gpu.DeviceModel(arch, C, size, size, 2, dtype='bf16', **opts)
         m.init_glorot(seed=2)
         plan_bytes = sum(b for k, b, f in m.plan() if k.startswith('bn_'))
         _, lg = m.forward(x, training=True, return_logits=True)
