@@ -811,10 +811,16 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
             // the producing conv left [rows][2C] float partials in the partials table (its epilogue saw every output value)
             const int rows = o.fused_stats_rows;
             o.fused_stats_rows = 0;
-            LAUNCH(m, "bn_fold_stats", 8.0 * rows * C, 0,
-                   hipLaunchKernelGGL((k_bn_fold_stats<8, float>), dim3((C + 7) / 8), dim3(1024), 0, m->stream, C, rows, (double)npix,
-                                      (const float*)m->bn_part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,
-                                      m->state + o.mv_off, o.coef, momentum, eps));
+            if (C <= 64)       // few channels: fewer channels per block, more row lanes
+                LAUNCH(m, "bn_fold_stats", 8.0 * rows * C, 0,
+                       hipLaunchKernelGGL((k_bn_fold_stats<2, float>), dim3((C + 1) / 2), dim3(1024), 0, m->stream, C, rows, (double)npix,
+                                          (const float*)m->bn_part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,
+                                          m->state + o.mv_off, o.coef, momentum, eps));
+            else
+                LAUNCH(m, "bn_fold_stats", 8.0 * rows * C, 0,
+                       hipLaunchKernelGGL((k_bn_fold_stats<8, float>), dim3((C + 7) / 8), dim3(1024), 0, m->stream, C, rows, (double)npix,
+                                          (const float*)m->bn_part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,
+                                          m->state + o.mv_off, o.coef, momentum, eps));
         } else {
             const unsigned nb = bn_blocks(npix, C);
             double* part = nullptr;
