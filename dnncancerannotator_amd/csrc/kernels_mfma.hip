@@ -805,6 +805,7 @@ struct PgPlan {                      // per-model table built lazily on the firs
     std::map<std::pair<const Op*, int>, int> wslot;  // (op, source) -> index into folds (transposed convs: source 0)
     int fold_chunks = 0;
     int nblocks_cap = 512;
+    bool nblocks_forced = false;       // DNNCA_NBLOCKS (tuning aid) overrides the occupancy-derived grids
     int nthreads = 512;
     bool double_buffer = true;
     unsigned long long* stamps = nullptr;
@@ -902,7 +903,7 @@ static int build_plan(Model* m, PgPlan& pl) {
     }
     pl.built = true;
     if (const char* e = getenv("DNNCA_DB")) pl.double_buffer = atoi(e) != 0;            // tuning aid
-    if (const char* e = getenv("DNNCA_NBLOCKS")) pl.nblocks_cap = atoi(e) > 0 ? atoi(e) : pl.nblocks_cap;   // tuning aid
+    if (const char* e = getenv("DNNCA_NBLOCKS")) { pl.nblocks_cap = atoi(e) > 0 ? atoi(e) : pl.nblocks_cap; pl.nblocks_forced = atoi(e) > 0; }   // tuning aid
     if (pl.folds.empty() && pl.descs.empty()) return DNNCA_OK;
     pl.fold_chunks = (max_out + 255) / 256;
     pl.slab_floats = slab_floats;
@@ -950,6 +951,18 @@ int fast_prepare(Model* m) {
     return DNNCA_OK;
 }
 
+// Grid of a persistent pixel-group kernel: as many 512-thread blocks as fit the chip at once (two per CU for the kernels whose
+// registers allow it, one for the heavy backward kernels -- launching 512 blocks of those ran them in two rounds and paid the
+// per-block prologue twice: 4-6 us on each of six kernels of the unet.yaml step).
+template <typename K>
+static int resident_blocks(K kernel, int cap) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    const int n = 256 * per_cu;
+    return n < cap ? n : cap;
+}
+
 #define CONV_SHAPES(X) X(1, 1, 3) X(3, 1, 3) X(3, 2, 3) X(3, 1, 6) X(6, 1, 6) X(6, 2, 6) X(6, 1, 12) X(12, 1, 12) X(12, 2, 12)
 
 bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool) {
@@ -975,9 +988,10 @@ bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool)
 #define X(c, ns, co)                                                                                            \
     if (C == c && NS == ns && CO == co) {                                                                       \
         (void)db;                                                                                               \
-        if (true)                                                                                               \
-            LAUNCH(m, "pgfwd_" #c "x" #ns "_" #co, bytes, flops,                                                \
-                   hipLaunchKernelGGL((k_pgfwd<c, ns, co, 512, false>), dim3(nb), dim3(512), 0, m->stream, a)); \
+        static const int fit = resident_blocks(k_pgfwd<c, ns, co, 512, false>, 1 << 20);                        \
+        const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);                                   \
+        LAUNCH(m, "pgfwd_" #c "x" #ns "_" #co, bytes, flops,                                                    \
+               hipLaunchKernelGGL((k_pgfwd<c, ns, co, 512, false>), dim3(g), dim3(512), 0, m->stream, a));      \
         return true;                                                                                            \
     }
     CONV_SHAPES(X)
@@ -1032,12 +1046,17 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
 #define X(c, ns, co)                                                                                            \
     if (C == c && NS == ns && CO == co) {                                                                       \
         (void)db;                                                                                               \
-        if (o.need_din)                                                                                    \
+        if (o.need_din) {                                                                                       \
+            static const int fit = resident_blocks(k_pgbwd<c, ns, co, true, 512, false>, 1 << 20);              \
+            const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);                               \
             LAUNCH(m, "pgbwd_" #c "x" #ns "_" #co, bytes, fl,                                                   \
-                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, true, 512, false>), dim3(nb), dim3(512), 0, m->stream, a)); \
-        else                                                                                                    \
+                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, true, 512, false>), dim3(g), dim3(512), 0, m->stream, a)); \
+        } else {                                                                                                \
+            static const int fit = resident_blocks(k_pgbwd<c, ns, co, false, 512, false>, 1 << 20);             \
+            const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);                               \
             LAUNCH(m, "pgbwd_w_" #c "x" #ns "_" #co, bytes, fl,                                                 \
-                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, false, 512, false>), dim3(nb), dim3(512), 0, m->stream, a)); \
+                   hipLaunchKernelGGL((k_pgbwd<c, ns, co, false, 512, false>), dim3(g), dim3(512), 0, m->stream, a)); \
+        }                                                                                                       \
         return true;                                                                                            \
     }
     CONV_SHAPES(X)
