@@ -951,14 +951,15 @@ int fast_prepare(Model* m) {
     return DNNCA_OK;
 }
 
-// Grid of a persistent pixel-group kernel: as many 512-thread blocks as fit the chip at once (two per CU for the kernels whose
+// Grid of a persistent pixel-group kernel: as many 512-thread blocks as fit the chip at once (two or three per CU for the kernels whose
 // registers allow it, one for the heavy backward kernels -- launching 512 blocks of those ran them in two rounds and paid the
 // per-block prologue twice: 4-6 us on each of six kernels of the unet.yaml step).
 template <typename K>
 static int resident_blocks(K kernel, int cap) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
+    static const int maxocc = getenv("DNNCA_PG_MAXOCC") ? atoi(getenv("DNNCA_PG_MAXOCC")) : 3;      // tuning aid (2: -0.3 %, 4: same)
+    if (per_cu > maxocc) per_cu = maxocc;
     const int n = 256 * per_cu;
     return n < cap ? n : cap;
 }
