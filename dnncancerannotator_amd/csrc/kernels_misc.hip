@@ -312,6 +312,87 @@ __global__ __launch_bounds__(256) void k_head_train(HeadArgs p) {
     }
 }
 
+// The same for wide heads (C = 16, 64): C / 4 adjacent lanes share a pixel, each holds four channels -- every load and store
+// is one coalesced 16-byte access per lane (the one-thread-per-pixel kernel above walks 256-byte rows with 64 lanes at once
+// and keeps 4 C floats per thread); the logit is folded across the lane group with shuffles.  Same partials layout.
+template <int C>
+__global__ __launch_bounds__(256) void k_head_train_wide(HeadArgs p) {
+    constexpr int G = C / 4, PPW = 64 / G, U = 4;        // lanes per pixel, pixels per wave and load, loads in flight
+    static_assert(C % 4 == 0 && 64 % G == 0, "lane groups");
+    __shared__ float red[4][C + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cq = lane % G, pl = lane / G;
+    const float4 wv = *reinterpret_cast<const float4*>(p.w + 4 * cq);
+    const float bias = p.bias[0];
+    float wgt;
+    if (p.cfg.has_weight) {
+        wgt = p.cfg.weight;
+    } else {
+        float pr = (float)(p.scalars[0] / p.n_label);
+        wgt = pr > 0.f ? 1.0f / pr : 1.0f;
+    }
+    wgt = p.cfg.weight_mul * wgt + p.cfg.weight_add;
+
+    float4 sdw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sdb = 0.f, sloss = 0.f;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;          // global wave index / count
+    for (int p0 = gw * (PPW * U); p0 < p.n4; p0 += nw * (PPW * U)) {
+        float4 f[U];
+        float z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = p0 + u * PPW + pl;
+            f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[u] = 0.f;
+            if (px < p.n4) {
+                f[u] = *reinterpret_cast<const float4*>(p.feat + (size_t)px * C + 4 * cq);
+                z[u] = p.y[px];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = p0 + u * PPW + pl;
+            float x = fmaf(f[u].x, wv.x, fmaf(f[u].y, wv.y, fmaf(f[u].z, wv.z, f[u].w * wv.w)));
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);     // every lane of the group ends with the sum
+            x += bias;
+            const float mk = fmaf(z[u], wgt - 1.0f, 1.0f);
+            const float e = expf(-fabsf(x));
+            const float sig = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+            const bool ok = px < p.n4;
+            const float dl = ok ? mk * (sig - z[u]) * p.gscale : 0.f;
+            if (ok && cq == 0) {
+                sloss = fmaf(fmaxf(x, 0.f) - x * z[u] + log1pf(e), mk, sloss);
+                sdb += dl;
+            }
+            sdw.x = fmaf(f[u].x, dl, sdw.x); sdw.y = fmaf(f[u].y, dl, sdw.y);
+            sdw.z = fmaf(f[u].z, dl, sdw.z); sdw.w = fmaf(f[u].w, dl, sdw.w);
+            float4 d = make_float4(dl * wv.x, dl * wv.y, dl * wv.z, dl * wv.w);
+            if (p.mask) {
+                d.x *= f[u].x > 0.f ? 1.0f : p.alpha; d.y *= f[u].y > 0.f ? 1.0f : p.alpha;
+                d.z *= f[u].z > 0.f ? 1.0f : p.alpha; d.w *= f[u].w > 0.f ? 1.0f : p.alpha;
+            }
+            if (ok) *reinterpret_cast<float4*>(p.dfeat + (size_t)px * C + 4 * cq) = d;
+        }
+    }
+    // lanes with the same channel quad (lane % G) add up across the wave, then the four waves through LDS
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+        sdw.x += __shfl_xor(sdw.x, o, 64); sdw.y += __shfl_xor(sdw.y, o, 64);
+        sdw.z += __shfl_xor(sdw.z, o, 64); sdw.w += __shfl_xor(sdw.w, o, 64);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sdb += __shfl_xor(sdb, o, 64); sloss += __shfl_xor(sloss, o, 64); }
+    if (lane < G) {
+        red[wave][4 * cq] = sdw.x; red[wave][4 * cq + 1] = sdw.y; red[wave][4 * cq + 2] = sdw.z; red[wave][4 * cq + 3] = sdw.w;
+    }
+    if (lane == 0) { red[wave][C] = sdb; red[wave][C + 1] = sloss; }
+    __syncthreads();
+    if (threadIdx.x < C + 2) {
+        const int k = threadIdx.x;
+        p.partials[blockIdx.x * (C + 2) + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
 // one block: sums the per-block partials of k_head_train in a fixed order (bit-reproducible) into the gradient vector
 template <int C>
 __global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ partials, int nblocks, float* dw, float* dbias,
@@ -366,7 +447,10 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
     a.partials = m->head_partials;
 #define HEAD_CASE(c, px)                                                                                               \
     if (C == c) {                                                                                                      \
-        LAUNCH(m, "head_train_" #c, bytes, 30.0 * npix, hipLaunchKernelGGL((k_head_train<c, px>), dim3(blocks), dim3(256), 0, m->stream, a)); \
+        if constexpr (c >= 16)                                                                                         \
+            LAUNCH(m, "head_train_" #c, bytes, 30.0 * npix, hipLaunchKernelGGL((k_head_train_wide<c>), dim3(blocks), dim3(256), 0, m->stream, a)); \
+        else                                                                                                           \
+            LAUNCH(m, "head_train_" #c, bytes, 30.0 * npix, hipLaunchKernelGGL((k_head_train<c, px>), dim3(blocks), dim3(256), 0, m->stream, a)); \
         if (m->head_defer_ok && m->merged_launches()) {       /* reduced by the launch that ends the backward pass (k_pg_fold) */ \
             m->head_pending.partials = m->head_partials; m->head_pending.nblocks = blocks; m->head_pending.C = c;       \
             m->head_pending.dw = a.dw; m->head_pending.dbias = a.dbias;                                                \
