@@ -1090,12 +1090,28 @@ __global__ void k_igb_prep(const PrepDesc* __restrict__ descs, const float* __re
         }
         return;
     }
-    const int n = 9 * d.cin * d.cout;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int co = i % d.cout, ci = (i / d.cout) % d.cin, t = i / (d.cin * d.cout);
-        const float v = params[d.w_off + i];
-        wf[d.w_off + ((size_t)t * d.cout + co) * d.cin + ci] = (bf16_t)v;
-        wd[d.w_off + ((size_t)(8 - t) * d.cin + ci) * d.cout + co] = (bf16_t)v;
+    // 3x3 kernels [t][ci][co] (channel counts are multiples of 32 under bf16): the data-gradient copy keeps co contiguous, the
+    // forward copy wants ci contiguous -- 32 x 32 tiles go through LDS so that both copies are written in 64-byte runs
+    // (element-wise scattered 2-byte stores made this the slowest bookkeeping kernel of the unet_big step: 109 us)
+    __shared__ float tile[32][33];
+    const int ntx = d.cout / 32, nty = d.cin / 32, ntiles = 9 * nty * ntx;
+    const int tx32 = threadIdx.x & 31, ty8 = threadIdx.x >> 5;          // 256 threads: 8 rows of 32
+    for (int id = blockIdx.x; id < ntiles; id += gridDim.x) {
+        const int t = id / (nty * ntx), r = id - t * (nty * ntx), ty = r / ntx, tx = r - ty * ntx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = ty * 32 + ty8 + 8 * k, co = tx * 32 + tx32;
+            const float v = params[d.w_off + ((size_t)t * d.cin + ci) * d.cout + co];
+            tile[ty8 + 8 * k][tx32] = v;
+            wd[d.w_off + ((size_t)(8 - t) * d.cin + ci) * d.cout + co] = (bf16_t)v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = tx * 32 + ty8 + 8 * k, ci = ty * 32 + tx32;
+            wf[d.w_off + ((size_t)t * d.cout + co) * d.cin + ci] = (bf16_t)tile[tx32][ty8 + 8 * k];
+        }
+        __syncthreads();
     }
 }
 
