@@ -14,7 +14,7 @@ bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool)
 bool fast_pool_fusable(const Model* m, const Op& conv, const Op& pool);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 // kernels_first.hip: the one-channel-input 3x3 convs (first layer of every encoder)
-bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops);
+bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);   // bn_next as for ig_conv_fwd
 bool fast_first_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 bool fast_pool_fwd(Model* m, int B, Op& o, double bytes);
 bool fast_pool_bwd(Model* m, int B, Op& o, double bytes);
@@ -42,7 +42,7 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
 bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 bool bn_scratch(Model* m, size_t bytes, void** out);       // the model's BN partials table, grown on demand
 bool ig_tconv_supported(const Model* m, const Op& o);
-bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops);
+bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);
 bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);   // decides maskA/maskB/premasked for every op (static per model)
 
 }  // namespace dnnca

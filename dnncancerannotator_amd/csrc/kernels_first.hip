@@ -28,6 +28,7 @@ struct Args {
     float alpha;         // forward: activation slope (<0 none).  backward: slope of act' when `mask`
     int mask;
     int nbuckets, bucket_stride;     // backward: block b adds into copy b % nbuckets (copies bucket_stride floats apart)
+    float* bn_part;      // forward: [blocks][2 CO] partial sums / sums of squares of the output for the BatchNorm behind it (or nullptr)
 };
 
 __device__ __forceinline__ void stage_patch(const Args& p, float* xs, int b, int y0, int x0) {
@@ -42,7 +43,9 @@ __device__ __forceinline__ void stage_patch(const Args& p, float* xs, int b, int
 
 __global__ __launch_bounds__(256) void k_first_fwd(Args p) {
     __shared__ float xs[PH * PW];
+    __shared__ float red[256][8];
     const int G = p.CO >> 2, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), bq = make_float4(0.f, 0.f, 0.f, 0.f);      // batch statistics of this thread's outputs
     float4 w[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(p.w + t * p.CO + 4 * cq);
@@ -67,6 +70,19 @@ __global__ __launch_bounds__(256) void k_first_fwd(Args p) {
                 a.z = a.z > 0.f ? a.z : p.alpha * a.z; a.w = a.w > 0.f ? a.w : p.alpha * a.w;
             }
             *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + y0 + ly) * p.W + x0 + lx) * p.CO + 4 * cq) = a;
+            bs.x += a.x; bs.y += a.y; bs.z += a.z; bs.w += a.w;
+            bq.x = fmaf(a.x, a.x, bq.x); bq.y = fmaf(a.y, a.y, bq.y); bq.z = fmaf(a.z, a.z, bq.z); bq.w = fmaf(a.w, a.w, bq.w);
+        }
+    }
+    if (p.bn_part) {        // one partial row per block: [sums (CO), sums of squares (CO)] (the layout of the conv kernels' rows)
+        red[threadIdx.x][0] = bs.x; red[threadIdx.x][1] = bs.y; red[threadIdx.x][2] = bs.z; red[threadIdx.x][3] = bs.w;
+        red[threadIdx.x][4] = bq.x; red[threadIdx.x][5] = bq.y; red[threadIdx.x][6] = bq.z; red[threadIdx.x][7] = bq.w;
+        __syncthreads();
+        for (int o = threadIdx.x; o < 2 * p.CO; o += 256) {
+            const int c = o % p.CO, which = o / p.CO;
+            float acc = 0.f;
+            for (int l = 0; l < PL; ++l) acc += red[l * G + (c >> 2)][4 * which + (c & 3)];
+            p.bn_part[(size_t)blockIdx.x * 2 * p.CO + o] = acc;
         }
     }
 }
@@ -171,11 +187,20 @@ static first::Args first_args(Model* m, int B, Op& o) {
     return a;
 }
 
-bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
+bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next) {
     if (!first_supported(o)) return false;
     first::Args a = first_args(m, B, o);
     a.alpha = o.alpha;
     const int blocks = a.ntiles < 4096 ? a.ntiles : 4096;
+    if (bn_next && !getenv("DNNCA_NO_BN_FUSION")) {      // the BatchNorm behind this conv takes its batch statistics from here
+        void* part = nullptr;
+        if (m->dry) {
+            bn_next->fused_stats_rows = blocks;
+        } else if (bn_scratch(m, (size_t)blocks * 2 * a.CO * 4, &part)) {
+            a.bn_part = (float*)part;
+            bn_next->fused_stats_rows = blocks;
+        }
+    }
     LAUNCH(m, "first_fwd", bytes, flops, hipLaunchKernelGGL(first::k_first_fwd, dim3(blocks), dim3(256), 0, m->stream, a));
     return true;
 }

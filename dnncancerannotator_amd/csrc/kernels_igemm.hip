@@ -730,6 +730,7 @@ struct TcArgs {
     int npix;                // B*H*W
     int psplit;
     float alpha;
+    float* bn_part;          // forward (bf16 kernel): [pixel block][2 * cout] partial batch statistics of the output for the BatchNorm behind it
 };
 
 __device__ __forceinline__ size_t tc_outpix(int p, int a, int e, int H, int W) {
@@ -1856,9 +1857,13 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t
                 for (int r = 0; r < 2; ++r) acc[ae][r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[r], bv, acc[ae][r][j], 0, 0, 0);
             }
     }
-    float bias[4];
+    float bias[4], bs[4], bq[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias[j] = p.bias[co0 + 16 * j + m16];
+    for (int j = 0; j < 4; ++j) {
+        bias[j] = p.bias[co0 + 16 * j + m16];
+        bs[j] = 0.f;
+        bq[j] = 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1869,9 +1874,29 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t
             for (int ae = 0; ae < 4; ++ae) {
                 float* op = p.out + tc_outpix(px, ae >> 1, ae & 1, p.H, p.W) * p.cout + co0 + m16;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) op[16 * j] = acc[ae][r][j][i] + bias[j];
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[ae][r][j][i] + bias[j];
+                    op[16 * j] = v;
+                    bs[j] += v;
+                    bq[j] = fmaf(v, v, bq[j]);
+                }
             }
         }
+    if (p.bn_part) {        // batch statistics for the BatchNorm behind the transposed conv: one row per pixel block
+        __shared__ float red[4][128];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bs[j] += __shfl_xor(bs[j], 16); bs[j] += __shfl_xor(bs[j], 32);
+            bq[j] += __shfl_xor(bq[j], 16); bq[j] += __shfl_xor(bq[j], 32);
+            if (q == 0) { red[wave][16 * j + m16] = bs[j]; red[wave][64 + 16 * j + m16] = bq[j]; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float a = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            const int half = tid >> 6, c = tid & 63;
+            p.bn_part[(size_t)blockIdx.x * (2 * p.cout) + half * p.cout + co0 + c] = a;
+        }
+    }
 }
 
 // data gradient: din[p][ci] = sum_{ae,co} dout[out(p,ae)][co] * W[ae][co][ci]; block = 128 pixels x 64 input channels,
@@ -2472,11 +2497,21 @@ static ig::TcArgs tc_args(Model* m, int B, Op& o) {
     return a;
 }
 
-bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops) {
+bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next) {
     if (!ig_tconv_supported(m, o)) return false;
     ig::TcArgs a = tc_args(m, B, o);
     if (use_bf16_tc(m, o)) {
         IgPlan& pl = g_ig[m];
+        if (bn_next && !getenv("DNNCA_NO_BN_FUSION")) {      // batch statistics of the BatchNorm behind it ride in the epilogue
+            const int rows = (a.npix + 127) / 128;
+            void* part = nullptr;
+            if (m->dry) {
+                bn_next->fused_stats_rows = rows;
+            } else if (bn_scratch(m, (size_t)rows * 2 * a.cout * 4, &part)) {
+                a.bn_part = (float*)part;
+                bn_next->fused_stats_rows = rows;
+            }
+        }
         const dim3 grid((a.npix + 127) / 128, a.cout / 64);
         if (o.inA.d.h)
             LAUNCH(m, "igb_tconv_fwd", bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_fwd<true>, grid, dim3(256), 0, m->stream, a, pl.wf + o.w_off));

@@ -398,7 +398,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 }
                 Op* bn_next = (training && oi + 1 < ops.size() && ops[oi + 1].type == OP_BN && ops[oi + 1].inA.d.p == o.out.d.p &&
                                fast_bn_supported(this, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
-                if (!generic && (fast_first_conv_fwd(this, B, o, bytes, flops) || ig_conv_fwd(this, B, o, bytes, flops, bn_next))) break;
+                if (!generic && (fast_first_conv_fwd(this, B, o, bytes, flops, bn_next) || ig_conv_fwd(this, B, o, bytes, flops, bn_next))) break;
                 if (!all_f32(o)) return DNNCA_ESTATE;
                 LAUNCH(this, "g_conv_fwd", bytes, flops,
                        g_conv_fwd(stream, B, o.inA.d, o.inB.d, p + o.w_off, p + o.b_off, o.out.d, o.k, o.alpha));
@@ -436,7 +436,9 @@ int Model::forward(const float* x_dev, int B, bool training) {
             case OP_TCONV: {
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
                 double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
-                if (!generic && (fast_tconv_fwd(this, B, o, bytes, flops) || ig_tconv_fwd(this, B, o, bytes, flops))) break;
+                Op* bn_next = (training && oi + 1 < ops.size() && ops[oi + 1].type == OP_BN && ops[oi + 1].inA.d.p == o.out.d.p &&
+                               fast_bn_supported(this, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
+                if (!generic && (fast_tconv_fwd(this, B, o, bytes, flops) || ig_tconv_fwd(this, B, o, bytes, flops, bn_next))) break;
                 if (!all_f32(o)) return DNNCA_ESTATE;
                 LAUNCH(this, "g_tconv_fwd", bytes, flops,
                        g_tconv_fwd(stream, B, o.inA.d, p + o.w_off, p + o.b_off, o.out.d, o.k));
