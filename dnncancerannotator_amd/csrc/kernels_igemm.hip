@@ -361,14 +361,18 @@ __global__ __launch_bounds__(256) void k_ig_wgrad(WgArgs p) {
 constexpr unsigned WG_FLAGS = 0x00020000u, WG_OOB = 0x80000000u;
 typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MW, int NN>
-__global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
-    constexpr int CIT = 16 * MW, COT = 16 * NN, WK = 4 / MW;
+// NWV = 8: eight waves (two per SIMD), the additional four split the tile's pixels (K) further -- for the narrow tiles whose
+// accumulators leave room (NN <= 2): the fp32 matrix pipe of a CU then has a second wave to issue from while the first waits.
+template <int MW, int NN, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
+    constexpr int NT = 64 * NWV;
+    constexpr int CIT = 16 * MW, COT = 16 * NN, WK = NWV / MW;
     constexpr int TM = (4 / MW) < (4 / NN) ? (4 / MW) : (4 / NN);
     constexpr int TYW = 8 * TM, PW = TX + 2, PPATCH = (TYW + 2) * PW, NPX = TYW * TX;
     constexpr int XS = CIT + (CIT == 16 ? 0 : 16), GS = COT + (COT == 16 ? 0 : 16);   // row strides = 16 (mod 32) banks
     constexpr int XQ = CIT / 4, GQ = COT / 4;                                           // float4 per pixel
-    constexpr int XU = (PPATCH * XQ + 255) / 256, GU = NPX * GQ / 256;
+    constexpr int XU = (PPATCH * XQ + NT - 1) / NT, GU = (NPX * GQ + NT - 1) / NT;
+    static_assert(NPX % (4 * WK) == 0 && (NPX / 4 / WK) % 2 == 0, "K-steps per wave");
     constexpr int NKS = NPX / 4 / WK;                                                   // K-steps per wave per tile
     constexpr int XF = PPATCH * XS + 16, GF = NPX * GS;
     constexpr int RF = MW * (9 * NN + 1) * 256;          // buffer of the in-block reduction (overlays the staged tiles)
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
         const int x0 = bx * TX, y0 = by * TYW;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int i = tid + 256 * u, px = i / XQ, c4 = i % XQ;
+            const int i = tid + NT * u, px = i / XQ, c4 = i % XQ;
             const int ly = px / PW, lx = px - ly * PW;
             const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
             const bool ok = px < PPATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
@@ -413,10 +417,10 @@ __global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int i = tid + 256 * u, px = i / GQ, n4 = i % GQ;
+            const int i = tid + NT * u, px = i / GQ, n4 = i % GQ;
             const int ly = px / TX, lx = px - ly * TX;
             const int iy = y0 + ly, ix = x0 + lx;
-            const bool ok = iy < p.H && ix < p.W;
+            const bool ok = px < NPX && iy < p.H && ix < p.W;
             const unsigned off = (ok ? (unsigned)(((((b * p.H + iy) * p.W + ix) * p.cout) + co0 + 4 * n4) * 4) : WG_OOB) | oob;
             gr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsg, off, 0, 0);
         }
@@ -424,14 +428,14 @@ __global__ __launch_bounds__(256, 1) void k_ig_wgrad2(WgArgs p) {
     auto commit = [&]() {
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int i = tid + 256 * u, px = i / XQ, c4 = i % XQ;
+            const int i = tid + NT * u, px = i / XQ, c4 = i % XQ;
             // lanes past the patch (last element only) write into the 16-float dump row behind it
             *reinterpret_cast<wg_u32x4*>(x_lds + (px < PPATCH ? px * XS + 4 * c4 : PPATCH * XS + 4 * (c4 & 3))) = xr[u];
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int i = tid + 256 * u, px = i / GQ, n4 = i % GQ;
-            *reinterpret_cast<wg_u32x4*>(g_lds + px * GS + 4 * n4) = gr[u];
+            const int i = tid + NT * u, px = i / GQ, n4 = i % GQ;
+            if (px < NPX) *reinterpret_cast<wg_u32x4*>(g_lds + px * GS + 4 * n4) = gr[u];
         }
     };
     // operand words of K-step ks of this wave (4 pixels: tile row ks / 4, pixels 4 (ks % 4) ..)
@@ -2436,10 +2440,13 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             if (ps > nt2) ps = nt2;
             w.psplit = ps < 1 ? 1 : ps;
             dim3 g2(w.psplit, w.cs / (16 * mw), CO / (16 * nn));
-#define WG2(MWv, NNv) LAUNCH(m, "ig_wgrad2", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad2<MWv, NNv>), g2, dim3(256), 0, m->stream, w))
-            if (mw == 4) { if (nn == 4) WG2(4, 4); else if (nn == 2) WG2(4, 2); else WG2(4, 1); }
-            else if (mw == 2) { if (nn == 4) WG2(2, 4); else if (nn == 2) WG2(2, 2); else WG2(2, 1); }
-            else { if (nn == 4) WG2(1, 4); else if (nn == 2) WG2(1, 2); else WG2(1, 1); }
+            static const int wg2_narrow = getenv("DNNCA_WGRAD2_NARROW") != nullptr;        // tuning aid
+#define WG2(MWv, NNv, NWv) LAUNCH(m, "ig_wgrad2", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad2<MWv, NNv, NWv>), g2, dim3(64 * NWv), 0, m->stream, w))
+#define WG2N(MWv) do { if (nn == 4) WG2(MWv, 4, 4); \
+                       else if (nn == 2) { if (wg2_narrow) WG2(MWv, 2, 4); else WG2(MWv, 2, 8); } \
+                       else { if (wg2_narrow) WG2(MWv, 1, 4); else WG2(MWv, 1, 8); } } while (0)
+            if (mw == 4) WG2N(4); else if (mw == 2) WG2N(2); else WG2N(1);
+#undef WG2N
 #undef WG2
         } else if (use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
         else if (use_bf16(m, o) && nn == 2) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<2>), grid, dim3(256), 0, m->stream, w));
