@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_wg_fold(float* __restrict__ slabs, int 
 // scheme).  Block tile 16 x 16 pixels x 16*NN channels, K chunks of 16 input channels; per item 576*NN/4... MFMAs per
 // wave (4 M-tiles x NN N-tiles x 9 taps x 4 K-steps of v_mfma_f32_16x16x4_f32), walked dx-major: one step = (dx, K-step)
 // loads 6 A words that serve the three dy taps, operand words of step s+1 are loaded before the MFMAs of step s.
-constexpr int F3T = 16, F3PATCH = (F3T + 2) * (F3T + 2);       // tile edge, staged patch pixels
+constexpr int F3T = 16;                                         // tile width (columns); rows: 4 per wave
 constexpr int F3AS = CK + 4;                                    // A row stride (floats)
 
 // NW = 8 (NN <= 2: the two buffers of a 32-row tile fit): 32 x 16-pixel tiles, two waves per SIMD -- the second wave covers the
