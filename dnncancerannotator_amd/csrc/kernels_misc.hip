@@ -792,7 +792,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
     float sg[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
     constexpr int U = 4;            // 8 loads in flight per thread
     const size_t chunk = (size_t)U * PL, nfull = npix / chunk;
-    for (size_t k = blockIdx.x; k < nfull; k += gridDim.x) {
+    // chunks back to front: whichever kernel produced dy wrote it front to back, its tail is what the Infinity Cache still holds;
+    // the apply pass that follows walks front to back and finds this pass's last reads there
+    for (size_t kk = blockIdx.x; kk < nfull; kk += gridDim.x) {
+        const size_t k = nfull - 1 - kk;
         const size_t p = k * chunk + pl;
         float4 v[U], d[U];
 #pragma unroll
