@@ -123,6 +123,7 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
     const int m = lane & 15, q = lane >> 4, n = m;
     const int co = n % CO;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
 
     // B operand (one register per K-step) and bias first; drain them and hide their origin from the compiler:
     // otherwise hipcc keeps `s_waitcnt vmcnt(..0)` for these registers inside the tile loop, and since vmcnt retires in
@@ -142,6 +143,9 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
     unsigned okm = 0;          // in-image mask of the prefetched tile (the same for every source)
     int tile = blockIdx.x;
     auto decode = [&](int t, int& b, int& x0, int& y0) {
+        // blocks b, b + 8, b + 16 ... share an XCD (and its L2): give each XCD one contiguous eighth of the tile sequence, so
+        // that the halo rows of vertically adjacent tiles are fetched into the same L2
+        if (xcd_map) t = (t & 7) * (ntiles >> 3) + (t >> 3);
         const int bx = t % p.tiles_x, by = (t / p.tiles_x) % p.tiles_y;
         b = t / (p.tiles_x * p.tiles_y);
         x0 = bx * TW;
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4, n = m16;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
 
     // two constants in LDS (1.0 for the all-ones bias row of the weight-gradient A operand, 0.0 for padding rows and
     // padding columns): the MFMA operands are then plain LDS reads, no per-MFMA select
@@ -370,6 +375,9 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     mpx.init(tid, p.W * C / 4);
     unsigned okg = 0, okx = 0;
     auto decode = [&](int t, int& b, int& x0, int& y0) {
+        // blocks b, b + 8, b + 16 ... share an XCD (and its L2): give each XCD one contiguous eighth of the tile sequence, so
+        // that the halo rows of vertically adjacent tiles are fetched into the same L2
+        if (xcd_map) t = (t & 7) * (ntiles >> 3) + (t >> 3);
         const int bx = t % p.tiles_x, by = (t / p.tiles_x) % p.tiles_y;
         b = t / (p.tiles_x * p.tiles_y);
         x0 = bx * TW;
