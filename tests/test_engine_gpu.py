@@ -127,6 +127,32 @@ def test_full_size_tuned_vs_generic_and_directional_derivative(gpu):
     generic.close()
 
 
+def test_full_size_batch_permutation_and_determinism(gpu):
+    """BASELINE size (8 x 512 x 512 x 1), size-independent properties of the tuned path: the forward pass is bit-reproducible;
+    permuting the slices of the batch permutes the logits exactly (no BatchNorm in configs/unet.yaml: slices are independent)
+    and leaves loss and gradients unchanged up to the summation order of the float atomics; the per-slice results do not
+    depend on which tile / block / XCD processed them."""
+    from dnncancerannotator_amd.synthetic import synthetic_batch
+    B, H, W = 8, 512, 512
+    x, y = synthetic_batch(B, H, W, 1)
+    m = gpu.DeviceModel('unet', 1, H, W, B, **UNET)
+    m.init_glorot(seed=2)
+    cfg = m.loss_cfg(weight_mul=3.0)
+    _, l0 = m.forward(x, training=False, return_logits=True)
+    _, l1 = m.forward(x, training=False, return_logits=True)
+    assert np.array_equal(l0, l1)
+    perm = np.array([5, 2, 7, 0, 3, 6, 1, 4])
+    _, lp = m.forward(np.ascontiguousarray(x[perm]), training=False, return_logits=True)
+    assert np.array_equal(lp, l0[perm])
+    o0 = m.train_step(x, y, 0.0, cfg)
+    g0 = m.get_grads().copy()
+    o1 = m.train_step(np.ascontiguousarray(x[perm]), np.ascontiguousarray(y[perm]), 0.0, cfg)
+    g1 = m.get_grads()
+    assert abs(o0.loss - o1.loss) <= 1e-6 * max(1.0, abs(o0.loss))
+    assert Hp.rel_err(g1, g0) <= 1e-5
+    m.close()
+
+
 @pytest.mark.parametrize('arch, C, opts, B, size', [
     ('unet', 1, dict(n_filters_first=64, n_downsample=4, bn=True), 1, 64),        # configs/unet_big.yaml
     ('mulmo', 3, dict(n_filters_first=16, n_downsample=4, bn=True), 2, 64),       # configs/mulmo_unet.yaml
