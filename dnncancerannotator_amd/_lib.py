@@ -92,12 +92,13 @@ SIGNATURES = {
     'dnnca_last_step_out': (C.c_int, [_VP, C.POINTER(StepOut)]),
     'dnnca_sync': (C.c_int, [_VP]),
     'dnnca_pixel_confusion': (C.c_int, [_VP, _FP, C.c_int, _FP, C.c_int, C.POINTER(Confusion)]),
+    'dnnca_pixel_confusion_of': (C.c_int, [_VP, _FP, _FP, C.c_int64, _FP, C.c_int, C.POINTER(Confusion)]),
     'dnnca_comm_unique_id': (C.c_int, [_VP]),
     'dnnca_comm_init': (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_size_t]),
     'dnnca_comm_world': (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'dnnca_comm_broadcast_weights': (C.c_int, [_VP, C.c_int]),
     'dnnca_comm_average_state': (C.c_int, [_VP]),
-    'dnnca_comm_allreduce_host': (C.c_int, [_VP, _FP, C.c_int, C.c_int]),
+    'dnnca_comm_allreduce_host': (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int64, C.c_int]),
     'dnnca_timer_start': (C.c_int, [_VP]),
     'dnnca_timer_stop': (C.c_int, [_VP, C.POINTER(C.c_float)]),
     'dnnca_profile_enable': (C.c_int, [_VP, C.c_int]),

@@ -54,7 +54,9 @@ void g_adam(hipStream_t s, size_t n, float* p, const float* g, float* m, float* 
             float eps, float gscale);
 void g_adam_finalize(hipStream_t s, size_t n, float* p, const float* g, float* m, float* v, float lr_t, float b1, float b2, float eps,
                      float gscale, double* scalars, const dnnca_loss_cfg cfg, double n_label, double inv_batch_hw, float* out5);
-void g_confusion(hipStream_t s, size_t n, const float* prob, const float* y, const float* thr, int nthr, double* out4);
+constexpr int DNNCA_CONF_MAX_THR = 1024;
+void g_confusion_hist(hipStream_t s, size_t n, const float* prob, const float* y, const float* thr_sorted, int nthr,
+                      unsigned long long* hist /* [2][nthr + 1], zeroed */);
 void g_scale(hipStream_t s, size_t n, float* p, float a);
 // zeroes a[0..na) and b[0..nb) (either may be empty) and resets the scalar block, in one launch
 void g_step_init(hipStream_t s, double* scalars, float* a, size_t na, float* b, size_t nb);

@@ -678,41 +678,51 @@ void g_adam_finalize(hipStream_t s, size_t n, float* p, const float* g, float* m
 }
 
 // ------------------------------------------------------------------------------------------------ pixel confusion
-__global__ void k_confusion(size_t n, const float* __restrict__ prob, const float* __restrict__ y,
-                            const float* __restrict__ thr, int nthr, double* __restrict__ out4) {
-    size_t T = (size_t)gridDim.x * TB;
-    for (int t = 0; t < nthr; ++t) {
-        float th = thr[t];
-        unsigned tp = 0, fp = 0, fn = 0, tn = 0;
-        for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += T) {
-            bool pp = prob[i] > th;       // Keras Precision/Recall: y_pred > threshold
-            bool yy = y[i] > 0.5f;        // labels are cast to bool [TF-2.6 metrics_utils]
-            tp += pp && yy;
-            fp += pp && !yy;
-            fn += !pp && yy;
-            tn += !pp && !yy;
+// One pass over (prob, y) for ANY number of thresholds: with the thresholds sorted ascending, bin(p) = #{t : thr[t] < p}
+// and "p > thr[t]" (the Keras Precision/Recall/AUC comparison, metrics.yaml:2-23) holds exactly for t < bin(p), so the
+// per-threshold counts are suffix sums of a (positive, negative) histogram over bins 0..nthr -- finished on the host in
+// exact 64-bit integers.  Integer work: bit-exact against numpy by construction.  HBM-bound: 8 B per pixel, read once.
+// NaN probabilities compare false against everything and land in bin 0, as `nan > t` does.
+__global__ __launch_bounds__(256) void k_confusion_hist(size_t n, const float* __restrict__ prob, const float* __restrict__ y,
+                                                        const float* __restrict__ thr, int nthr,
+                                                        unsigned long long* __restrict__ hist /* [2][nthr + 1] */) {
+    __shared__ float sthr[DNNCA_CONF_MAX_THR];
+    __shared__ unsigned h[2][DNNCA_CONF_MAX_THR + 1];
+    for (int i = threadIdx.x; i < nthr; i += 256) sthr[i] = thr[i];
+    for (int i = threadIdx.x; i < 2 * (DNNCA_CONF_MAX_THR + 1); i += 256) (&h[0][0])[i] = 0u;
+    __syncthreads();
+    // most pixels of a segmentation map sit below every threshold or above all of them: those two bins stay in registers
+    unsigned lo[2] = {0u, 0u}, hi[2] = {0u, 0u};
+    size_t T = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += T) {
+        float p = prob[i];
+        int yy = y[i] > 0.5f ? 0 : 1;          // labels are cast to bool [TF-2.6 metrics_utils]; row 0 = positives
+        int a = 0, b = nthr;                   // first index with !(thr[idx] < p)
+        while (a < b) {
+            int mid = (a + b) >> 1;
+            if (sthr[mid] < p) a = mid + 1; else b = mid;
         }
-        double d0 = wave_sum_d((double)tp), d1 = wave_sum_d((double)fp), d2 = wave_sum_d((double)fn),
-               d3 = wave_sum_d((double)tn);
-        // block-level sums first: one atomic per block and counter (same-address atomics serialise)
-        __shared__ double red[TB / 64][4];
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) {
-            red[threadIdx.x >> 6][0] = d0; red[threadIdx.x >> 6][1] = d1; red[threadIdx.x >> 6][2] = d2; red[threadIdx.x >> 6][3] = d3;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            double a = 0.0;
-            for (int w = 0; w < TB / 64; ++w) a += red[w][threadIdx.x];
-            atomicAdd(out4 + 4 * t + threadIdx.x, a);
-        }
+        if (a == 0) ++lo[yy];
+        else if (a == nthr) ++hi[yy];
+        else atomicAdd(&h[yy][a], 1u);
+    }
+    for (int r = 0; r < 2; ++r) {
+        if (lo[r]) atomicAdd(&h[r][0], lo[r]);
+        if (hi[r]) atomicAdd(&h[r][nthr], hi[r]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * (nthr + 1); i += 256) {
+        int r = i / (nthr + 1), bin = i - r * (nthr + 1);
+        unsigned v = h[r][bin];
+        if (v) atomicAdd(hist + i, (unsigned long long)v);
     }
 }
 
-void g_confusion(hipStream_t s, size_t n, const float* prob, const float* y, const float* thr, int nthr, double* out4) {
-    unsigned blocks = nblk(n, TB * 16);
-    if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(k_confusion, dim3(blocks), dim3(TB), 0, s, n, prob, y, thr, nthr, out4);
+void g_confusion_hist(hipStream_t s, size_t n, const float* prob, const float* y, const float* thr_sorted, int nthr,
+                      unsigned long long* hist) {
+    unsigned blocks = nblk(n, 256 * 16);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_confusion_hist, dim3(blocks), dim3(256), 0, s, n, prob, y, thr_sorted, nthr, hist);
 }
 
 // one launch at the top of a step: scalar block, flat gradient vector and the weight-gradient slabs

@@ -2321,7 +2321,11 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
         a2.tiles_y = (a.H + 4 * nw - 1) / (4 * nw);
         const unsigned nblocks = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / 64));
         const unsigned g = nblocks < 256u ? nblocks : 256u;
-#define IGB3(A16v, NWv) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE, A16v, NWv>), dim3(g), dim3(64 * NWv), 0, m->stream, a2, w16))
+        // the launch name carries the variant (waves per block, bf16-stored source) so that tests and profiles can tell
+        // which instantiation ran: igb_conv_fwd_w8 / _w4 [+ _a16]
+        char vname[64];
+        snprintf(vname, sizeof(vname), "%s_w%d%s", name, nw, a.src_half ? "_a16" : "");
+#define IGB3(A16v, NWv) LAUNCH(m, vname, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv3<MODE, A16v, NWv>), dim3(g), dim3(64 * NWv), 0, m->stream, a2, w16))
         if (a.src_half) { if (nw == 8) IGB3(true, 8); else IGB3(true, 4); }
         else { if (nw == 8) IGB3(false, 8); else IGB3(false, 4); }
 #undef IGB3

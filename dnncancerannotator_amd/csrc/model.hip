@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 
 #include "fast.h"
@@ -335,9 +336,9 @@ int Model::build() {
     DN_TRY(alloc((void**)&logits, npix * 4));
     DN_TRY(alloc((void**)&dlogits, npix * 4));
     DN_TRY(alloc((void**)&prob, npix * 4));
-    DN_TRY(alloc((void**)&thr_dev, 256 * 4));
+    DN_TRY(alloc((void**)&thr_dev, DNNCA_CONF_MAX_THR * 4));
     DN_TRY(alloc((void**)&head_partials, 2048 * 72 * 4));
-    DN_TRY(alloc((void**)&conf_dev, 256 * 4 * 8));
+    DN_TRY(alloc((void**)&conf_dev, 2 * (DNNCA_CONF_MAX_THR + 1) * 8));     // confusion histogram / host all-reduce staging
     // Keras defaults for the non-trainable / BN variables: gamma 1, moving_variance 1 (the rest 0)
     {
         std::vector<float> hp((size_t)nT, 0.f), hs((size_t)nS, 0.f);
@@ -839,25 +840,65 @@ int dnnca_dev_free(void* dev_ptr) { HIP_TRY(hipFree(dev_ptr)); return DNNCA_OK; 
 int dnnca_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) { HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice)); return DNNCA_OK; }
 int dnnca_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) { HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost)); return DNNCA_OK; }
 
+static int confusion_counts(Model* M, size_t npix, const float* thresholds, int n, dnnca_confusion* out) {
+    // sort the thresholds (stable order of the caller is restored below); the kernel wants them ascending
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return thresholds[a] < thresholds[b]; });
+    std::vector<float> sorted(n);
+    for (int i = 0; i < n; ++i) {
+        sorted[i] = thresholds[order[i]];
+        if (sorted[i] != sorted[i]) { set_error("threshold %d is NaN", order[i]); return DNNCA_EINVAL; }
+    }
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(M->conf_dev);
+    size_t hbytes = (size_t)2 * (n + 1) * 8;
+    HIP_TRY(hipMemcpyAsync(M->thr_dev, sorted.data(), (size_t)n * 4, hipMemcpyHostToDevice, M->stream));
+    HIP_TRY(hipMemsetAsync(hist, 0, hbytes, M->stream));
+    g_confusion_hist(M->stream, npix, M->prob, M->y_stage, M->thr_dev, n, hist);
+    std::vector<unsigned long long> h((size_t)2 * (n + 1));
+    HIP_TRY(hipMemcpyAsync(h.data(), hist, hbytes, hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    const unsigned long long* pos = h.data();
+    const unsigned long long* neg = h.data() + (n + 1);
+    unsigned long long P = 0, N = 0;
+    for (int b = 0; b <= n; ++b) { P += pos[b]; N += neg[b]; }
+    unsigned long long tp = 0, fp = 0;            // suffix sums: prob > sorted[t]  <=>  bin > t
+    for (int t = n - 1; t >= 0; --t) {
+        tp += pos[t + 1];
+        fp += neg[t + 1];
+        dnnca_confusion& o = out[order[t]];
+        o.tp = (double)tp;
+        o.fp = (double)fp;
+        o.fn = (double)(P - tp);
+        o.tn = (double)(N - fp);
+    }
+    return DNNCA_OK;
+}
+
 int dnnca_pixel_confusion(void* model, const float* y_hw, int batch, const float* thresholds, int n, dnnca_confusion* out) {
     MODEL(model);
-    if (n < 1 || n > 256 || !out || !thresholds || !y_hw) { set_error("bad confusion arguments"); return DNNCA_EINVAL; }
+    if (n < 1 || n > DNNCA_CONF_MAX_THR || !out || !thresholds || !y_hw) {
+        set_error("bad confusion arguments (1..%d thresholds)", DNNCA_CONF_MAX_THR);
+        return DNNCA_EINVAL;
+    }
     if (batch < 1 || batch > M->desc.max_batch) { set_error("batch out of range"); return DNNCA_EINVAL; }
     size_t npix = (size_t)batch * M->outH * M->outW;
     HIP_TRY(hipMemcpyAsync(M->y_stage, y_hw, npix * 4, hipMemcpyHostToDevice, M->stream));
-    HIP_TRY(hipMemcpyAsync(M->thr_dev, thresholds, (size_t)n * 4, hipMemcpyHostToDevice, M->stream));
-    HIP_TRY(hipMemsetAsync(M->conf_dev, 0, (size_t)n * 4 * 8, M->stream));
-    g_confusion(M->stream, npix, M->prob, M->y_stage, M->thr_dev, n, M->conf_dev);
-    std::vector<double> h((size_t)n * 4);
-    HIP_TRY(hipMemcpyAsync(h.data(), M->conf_dev, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, M->stream));
-    HIP_TRY(hipStreamSynchronize(M->stream));
-    for (int i = 0; i < n; ++i) {
-        out[i].tp = h[4 * i];
-        out[i].fp = h[4 * i + 1];
-        out[i].fn = h[4 * i + 2];
-        out[i].tn = h[4 * i + 3];
+    return confusion_counts(M, npix, thresholds, n, out);
+}
+
+int dnnca_pixel_confusion_of(void* model, const float* prob_hw, const float* y_hw, int64_t n_pixels, const float* thresholds,
+                             int n, dnnca_confusion* out) {
+    MODEL(model);
+    if (n < 1 || n > DNNCA_CONF_MAX_THR || !out || !thresholds || !y_hw || !prob_hw) {
+        set_error("bad confusion arguments (1..%d thresholds)", DNNCA_CONF_MAX_THR);
+        return DNNCA_EINVAL;
     }
-    return DNNCA_OK;
+    int64_t cap = (int64_t)M->desc.max_batch * M->outH * M->outW;
+    if (n_pixels < 1 || n_pixels > cap) { set_error("n_pixels %lld outside 1..%lld", (long long)n_pixels, (long long)cap); return DNNCA_EINVAL; }
+    HIP_TRY(hipMemcpyAsync(M->prob, prob_hw, (size_t)n_pixels * 4, hipMemcpyHostToDevice, M->stream));
+    HIP_TRY(hipMemcpyAsync(M->y_stage, y_hw, (size_t)n_pixels * 4, hipMemcpyHostToDevice, M->stream));
+    return confusion_counts(M, (size_t)n_pixels, thresholds, n, out);
 }
 
 // ------------------------------------------------------------------------------------------------- data parallel
@@ -917,16 +958,23 @@ int dnnca_comm_average_state(void* model) {
     return DNNCA_OK;
 }
 
-int dnnca_comm_allreduce_host(void* model, float* values, int n, int op) {
+int dnnca_comm_allreduce_host(void* model, double* values, int64_t n, int op) {
     MODEL(model);
-    if (n < 1 || n > 256 || !values) return DNNCA_EINVAL;
+    if (n < 1 || !values) { set_error("dnnca_comm_allreduce_host: bad arguments (n = %lld)", (long long)n); return DNNCA_EINVAL; }
+    if (op != 0 && op != 1) { set_error("dnnca_comm_allreduce_host: op %d (0 sum, 1 max)", op); return DNNCA_EINVAL; }
     if (!M->comm) return DNNCA_OK;
-    float* tmp = reinterpret_cast<float*>(M->conf_dev);
-    HIP_TRY(hipMemcpyAsync(tmp, values, (size_t)n * 4, hipMemcpyHostToDevice, M->stream));
-    ncclResult_t r = ncclAllReduce(tmp, tmp, (size_t)n, ncclFloat, op == 1 ? ncclMax : ncclSum, M->comm, M->stream);
-    if (r != ncclSuccess) { set_error("ncclAllReduce(host): %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
-    HIP_TRY(hipMemcpyAsync(values, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, M->stream));
-    HIP_TRY(hipStreamSynchronize(M->stream));
+    // doubles: pixel counts of a whole validation set stay exact (float32 stops at 2^24 = 64 slices of 512 x 512);
+    // chunked through the confusion staging buffer, so any length works
+    double* tmp = reinterpret_cast<double*>(M->conf_dev);
+    const int64_t cap = 2 * (DNNCA_CONF_MAX_THR + 1);
+    for (int64_t off = 0; off < n; off += cap) {
+        size_t c = (size_t)std::min<int64_t>(cap, n - off);
+        HIP_TRY(hipMemcpyAsync(tmp, values + off, c * 8, hipMemcpyHostToDevice, M->stream));
+        ncclResult_t r = ncclAllReduce(tmp, tmp, c, ncclDouble, op == 1 ? ncclMax : ncclSum, M->comm, M->stream);
+        if (r != ncclSuccess) { set_error("ncclAllReduce(host): %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
+        HIP_TRY(hipMemcpyAsync(values + off, tmp, c * 8, hipMemcpyDeviceToHost, M->stream));
+        HIP_TRY(hipStreamSynchronize(M->stream));
+    }
     return DNNCA_OK;
 }
 

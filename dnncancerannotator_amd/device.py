@@ -272,6 +272,16 @@ class DeviceModel:
         check(self.lib.dnnca_pixel_confusion(self.handle, fptr(y), y.shape[0], fptr(thr), thr.size, out))
         return [(c.tp, c.fp, c.fn, c.tn) for c in out]
 
+    def pixel_confusion_of(self, prob, y, thresholds):
+        """Metric.update_state(y_true, y_pred) on caller-supplied probabilities: [(tp, fp, fn, tn)] per threshold (exact)."""
+        prob, y = as_f32(prob).ravel(), as_f32(y).ravel()
+        if prob.size != y.size:
+            raise ValueError('prob and y differ in size: %d vs %d' % (prob.size, y.size))
+        thr = as_f32(thresholds).ravel()
+        out = (_lib.Confusion * thr.size)()
+        check(self.lib.dnnca_pixel_confusion_of(self.handle, fptr(prob), fptr(y), prob.size, fptr(thr), thr.size, out))
+        return [(c.tp, c.fp, c.fn, c.tn) for c in out]
+
     # ---- device-side augmentation (annotator/data.py:62-111 train_ds) ------------------------------------------
     def augment_u8(self, raw, params, out_size, label_index, contrast_channels=None):
         """raw uint8 [B, Hs, Ws, Cs] (host) + per-image draws [(dy, dx, flip, contrast)] -> device-resident (x [B, Ho, Wo, Cs-1],
@@ -328,8 +338,8 @@ class DeviceModel:
         check(self.lib.dnnca_comm_average_state(self.handle))
 
     def comm_allreduce(self, values, op='sum'):
-        v = as_f32(values).ravel().copy()
-        check(self.lib.dnnca_comm_allreduce_host(self.handle, fptr(v), v.size, 1 if op == 'max' else 0))
+        v = np.array(values, dtype=np.float64).ravel()
+        check(self.lib.dnnca_comm_allreduce_host(self.handle, v.ctypes.data_as(C.POINTER(C.c_double)), v.size, 1 if op == 'max' else 0))
         return v
 
     # ---- measurement ------------------------------------------------------------------------------------------

@@ -65,10 +65,12 @@ def cleanup(ctx):
             pass
 
 
-def shard_bounds(n, rank, world):
-    """[begin, end) of this rank's contiguous shard of a global batch of n (n must divide evenly, like Keras requires
-    for a MirroredStrategy batch [TF-2.6])."""
-    if n % world:
+def shard_bounds(n, rank, world, even=True):
+    """[begin, end) of this rank's contiguous shard of a global batch of n.  even=True: n must divide evenly (a training
+    batch under MirroredStrategy [TF-2.6]); even=False: the first n % world ranks take one extra sample (the last, partial
+    batch of an evaluation set -- no sample is dropped)."""
+    if n % world and even:
         raise ValueError('global batch %d is not divisible by %d ranks' % (n, world))
-    per = n // world
-    return rank * per, (rank + 1) * per
+    per, rem = divmod(n, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)

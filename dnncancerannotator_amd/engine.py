@@ -42,8 +42,8 @@ def _element_shape(dataset):
     spec = getattr(dataset, 'element_spec', None)
     if spec is not None:
         return tuple(spec[0].shape)
-    for x, _ in dataset:
-        return tuple(np.shape(x))
+    for element in dataset:          # (x, y) for train / eval, (x,) for predict
+        return tuple(np.shape(element[0]))
     raise ValueError('empty dataset')
 
 
@@ -77,33 +77,73 @@ class TFKerasModel:
         self.adam = dict(beta1=0.9, beta2=0.999, epsilon=1e-7)
         return model
 
-    def _build(self, dataset, max_batch=None):
-        if self.device_model is not None:
-            return
+    def _build(self, dataset, max_batch=None, also=()):
+        """model.build(element_spec.shape) (engine.py:93).  `also`: further datasets that will be fed to this model (the
+        validation set of train(): configs/additionals/data_options.yaml has train batch 8, eval batch 64) -- the device
+        model is sized for the largest per-rank batch so that a validation batch is ONE eval step and its positive-rate
+        weight is computed over the whole per-replica batch, as utils/losses.py:24-27,87-95 does."""
         shape = _element_shape(dataset)
         global_batch = max_batch or shape[0]
         if global_batch is None:
             raise ValueError('dataset batch size unknown')
         if global_batch % self.ctx.world:
             raise ValueError('global batch %d is not divisible by %d ranks' % (global_batch, self.ctx.world))
+        per_rank = global_batch // self.ctx.world
+        for other in also:
+            if other is not None:
+                b = _element_shape(other)[0]
+                if b:
+                    per_rank = max(per_rank, -(-b // self.ctx.world))
+        if self.device_model is not None:
+            self._ensure_capacity(per_rank)
+            return
         device.init_device(self.ctx.local_rank)
         if self.enable_multigpu and self.ctx.world == 1 and device.device_count() > 1:
             logging.warning('enable_multigpu: %d GPUs visible but one process; launch with '
                             '`python -m dnncancerannotator_amd.launch --nproc N ...` for data parallel', device.device_count())
-        self.device_model = self.model.build([global_batch // self.ctx.world] + list(shape[1:]), seed=0)
+        self._input_shape = list(shape[1:])
+        self.device_model = self.model.build([per_rank] + self._input_shape, seed=0)
         self.device_model.set_adam(**self.adam)
+        self._join_ranks()
+
+    def _join_ranks(self):
         if self.ctx.world > 1:
             self.device_model.comm_init(self.ctx.rank, self.ctx.world, distributed.exchange_unique_id(self.ctx, device.DeviceModel))
+            distributed.cleanup(self.ctx)     # ncclCommInitRank returned: every rank has read the id file
             # identical initial weights on every replica (MirroredStrategy mirrors rank 0's variables)
             self.device_model.comm_broadcast_weights(0)
 
+    def _ensure_capacity(self, per_rank_batch):
+        """Grow the device model to `per_rank_batch` slices per step (weights, BN statistics and Adam slots carried over).
+        Returns False when HBM cannot hold it (the caller then evaluates in chunks)."""
+        dm = self.device_model
+        if per_rank_batch <= dm.max_batch:
+            return True
+        if self.ctx.world > 1:
+            return False      # the communicator belongs to the existing handle; _build sizes DP models up front
+        params, state, (m, v, it) = dm.get_params(), dm.get_state(), dm.get_opt_state()
+        try:
+            bigger = self.model.build([per_rank_batch] + self._input_shape, seed=0)
+        except Exception as e:           # out of HBM: keep the model we have
+            logging.warning('cannot size the model for a batch of %d (%s): evaluating in chunks', per_rank_batch, e)
+            self.model.device_model = dm
+            return False
+        dm.close()
+        bigger.set_params(params)
+        if bigger.n_state:
+            bigger.set_state(state)
+        bigger.set_opt_state(m, v, it)
+        bigger.set_adam(**self.adam)
+        self.device_model = bigger
+        return True
+
     def _shard(self, x, y=None):
-        """Contiguous shard of a global batch for this rank (Keras splits the batch across replicas [TF-2.6])."""
+        """Contiguous shard of a global batch for this rank (Keras splits the batch across replicas [TF-2.6]); a batch
+        that does not divide evenly (the last batch of an evaluation set) gives its remainder to the first ranks."""
         if self.ctx.world == 1:
             return x, y
-        n = len(x) // self.ctx.world
-        sl = slice(self.ctx.rank * n, (self.ctx.rank + 1) * n)
-        return x[sl], (None if y is None else y[sl])
+        lo, hi = distributed.shard_bounds(len(x), self.ctx.rank, self.ctx.world, even=False)
+        return x[lo:hi], (None if y is None else y[lo:hi])
 
     # ---- checkpoints (engine.py:55-78, 103-106, 224-231) -----------------------------------------------------
     def get_ckpts(self, base_path):
@@ -159,7 +199,7 @@ class TFKerasModel:
     # ---- training (engine.py:80-137) -------------------------------------------------------------------------
     def train(self, dataset, val_data=None, save_path=None, save_freq=100, max_steps=None, early_stop_steps=None,
               visualization=None, auto_resume=True, profile=False):
-        self._build(dataset)
+        self._build(dataset, also=(val_data,))
         dm = self.device_model
         if auto_resume and save_path is not None:
             self._auto_resume(os.path.join(save_path, 'checkpoints'))
@@ -232,27 +272,46 @@ class TFKerasModel:
 
     # ---- evaluation (engine.py:139-210) ----------------------------------------------------------------------
     def _evaluate(self, dataset):
-        """keras Model.evaluate(return_dict=True): mean loss over batches + pixel metrics, training=False."""
-        dm = self.device_model
-        cfg = dm.loss_cfg(**self.loss.device_cfg())
+        """keras Model.evaluate(return_dict=True): mean loss over batches + pixel metrics, training=False.  One batch of
+        the dataset is one test step per replica: the positive-rate class weight (utils/losses.py:24-27) is taken over the
+        whole per-replica batch, never over a chunk of it."""
+        cfg_kw = self.loss.device_cfg()
         for m in self.metrics:
             m.reset_state()
         total, count = 0.0, 0
         for x, y in dataset:
             x, y = self._shard(np.asarray(x), np.asarray(y))
-            if len(x) == 0:
-                continue
-            for i in range(0, len(x), dm.max_batch):
-                xb, yb = x[i:i + dm.max_batch], y[i:i + dm.max_batch]
-                out = dm.eval_step(xb, yb, cfg)
-                total += float(out.loss) * len(xb)
-                count += len(xb)
+            if len(x):
+                self._ensure_capacity(len(x))
+            dm = self.device_model
+            if 0 < len(x) <= dm.max_batch:
+                out = dm.eval_step(x, y, dm.loss_cfg(**cfg_kw))
+                total += float(out.loss) * len(x)
+                count += len(x)
                 for m in self.metrics:
-                    m.update_state(dm, yb)
+                    m.update_state(dm, y)
+            elif len(x):
+                # HBM cannot hold the batch in one step: chunks, each with the weight of the WHOLE batch passed explicitly
+                kw = dict(cfg_kw)
+                if kw.get('weight') is None:
+                    if kw.get('label_smoothing'):
+                        logging.warning('label smoothing + chunked validation: the class weight is taken per chunk')
+                    else:
+                        rate = float(np.asarray(y, np.float64).mean())
+                        kw['weight'] = 1.0 / rate if rate > 0 else 1.0          # utils/losses.py:25-27
+                cfg = dm.loss_cfg(**kw)
+                for i in range(0, len(x), dm.max_batch):
+                    xb, yb = x[i:i + dm.max_batch], y[i:i + dm.max_batch]
+                    out = dm.eval_step(xb, yb, cfg)
+                    total += float(out.loss) * len(xb)
+                    count += len(xb)
+                    for m in self.metrics:
+                        m.update_state(dm, yb)
         if self.ctx.world > 1:
+            dm = self.device_model
             total, count = (float(v) for v in dm.comm_allreduce([total, count]))
-            for m in self.metrics:
-                m.merge(lambda c: dm.comm_allreduce(c.ravel()).reshape(c.shape).astype(np.float64))
+            for m in self.metrics:                      # counts travel as doubles: exact far beyond 2^24 pixels
+                m.merge(lambda c: np.asarray(dm.comm_allreduce(c.ravel()), np.float64).reshape(c.shape))
         results = OrderedDict(loss=total / max(count, 1))
         for m in self.metrics:
             r = m.result()

@@ -159,6 +159,11 @@ int dnnca_sync(void* model);
 /* pixel TP/FP/FN/TN of the last forward/eval probabilities against y at n thresholds (metrics.yaml:2-23 pixel metrics;
  * utils/metrics.py:37-77 FBetaScore builds on them). y_hw is a host buffer [B,H,W]. */
 int dnnca_pixel_confusion(void* model, const float* y_hw, int batch, const float* thresholds, int n, dnnca_confusion* out);
+/* the same counts for probabilities the caller supplies: tf.keras.metrics.{Precision,Recall,AUC}.update_state(y_true, y_pred)
+ * as utils/metrics.py:53-56 calls it.  Both host buffers hold n_pixels floats (at most max_batch * H * W); any number of
+ * thresholds up to 1024 in any order (AUC(num_thresholds=150), metrics.yaml:8-15); counts are exact integers. */
+int dnnca_pixel_confusion_of(void* model, const float* prob_hw, const float* y_hw, int64_t n_pixels, const float* thresholds,
+                             int n, dnnca_confusion* out);
 
 /* ---- data parallel: tf.distribute.MirroredStrategy (engine.py:260-263) re-done as one process per GPU + RCCL ---- */
 int dnnca_comm_unique_id(void* id_out /* DNNCA_UNIQUE_ID_BYTES */);
@@ -166,7 +171,8 @@ int dnnca_comm_init(void* model, int rank, int world, const void* unique_id, siz
 int dnnca_comm_world(void* model, int* rank, int* world);
 int dnnca_comm_broadcast_weights(void* model, int root);   /* weights, BN statistics and Adam slots of `root` on every rank */
 int dnnca_comm_average_state(void* model);          /* BN moving statistics: mean over ranks before a checkpoint */
-int dnnca_comm_allreduce_host(void* model, float* values, int n, int op /* 0 sum, 1 max */);
+/* small host-side reductions (validation loss sums, metric counts: MirroredStrategy's metric aggregation); doubles, any length */
+int dnnca_comm_allreduce_host(void* model, double* values, int64_t n, int op /* 0 sum, 1 max */);
 
 /* ---- measurement: HIP events on the model's stream ------------------------------------------------------------- */
 int dnnca_timer_start(void* model);

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(HERE, '..'))
 
 from oracle import unet_oracle as O   # noqa: E402
 import torch_ref                      # noqa: E402
-from helpers import perturbed_params, PARAM_SEED   # noqa: E402
+from helpers import perturbed_params, tensor_slices, PARAM_SEED   # noqa: E402
 
 LEAKY = {'class_name': 'LeakyReLU', 'config': {'alpha': 0.3}}
 L2 = {'class_name': 'L2', 'config': {'l2': 0.01}}
@@ -53,7 +53,6 @@ CASES = {
 }
 
 LR = 1e-3
-SAMPLE_STRIDE = 97
 
 
 def make_case(name):
@@ -102,13 +101,15 @@ def make_case(name):
         torch_logit_err=np.float64(np.abs(logits - ref['logits']).max()),
     )
     pa = O.flatten(spec, new_params).astype(np.float32)
+    # full gradients for every case (the two big ones too: every variable is compared on its own scale)
+    out['grads'] = g64.astype(np.float32)
     if len(g64) <= 50000:
-        out['grads'] = g64.astype(np.float32)
-        out['params_after'] = pa
-    else:   # big models: strided samples keep the fixture small (weights are regenerated from the seed)
-        out['sample_stride'] = SAMPLE_STRIDE
-        out['grads_sample'] = g64[::SAMPLE_STRIDE].astype(np.float32)
-        out['params_after_sample'] = pa[::SAMPLE_STRIDE]
+        out['params_after'] = pa          # big cases: the test re-derives them with O.adam_step from `grads` (halves the fixture)
+    # what plain float32 numpy costs PER VARIABLE (max |g32 - g64| inside each tensor, absolute): the evidence the per-tensor
+    # tolerance of the GPU tests is derived from.  Variables whose gradient is analytically zero (a bias feeding a
+    # BatchNorm, the last BatchNorm of a mulmo encoder whose skips are unused) are pure rounding noise in any fp32
+    # implementation; this is their noise floor.
+    out['fp32_grad_abs_err_t'] = np.array([np.abs(g32[sl].astype(np.float64) - g64[sl]).max() for _, sl in tensor_slices(spec)])
     if store_params:
         out['params'] = O.flatten(spec, p64).astype(np.float32)
         out['state'] = O.flatten(spec, p64, trainable=False).astype(np.float32)

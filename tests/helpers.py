@@ -2,6 +2,7 @@
 
 import json
 import os
+from collections import OrderedDict
 
 import numpy as np
 
@@ -58,3 +59,102 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def tensor_slices(spec, trainable=True):
+    """[(name, slice)] of every variable inside the flat trainable (or state) vector, Keras creation order."""
+    out, off = [], 0
+    for n, shape, t in O.param_specs(spec):
+        if t != trainable:
+            continue
+        size = int(np.prod(shape))
+        out.append((n, slice(off, off + size)))
+        off += size
+    return out
+
+
+def per_tensor_err(spec, g, gref):
+    """{name: max|g - gref| / max|gref|} with BOTH maxima taken inside that variable's own slice -- a gradient tensor that
+    is small next to the head's gradient is judged against its own scale (components.py:46-52,118-127: every variable
+    gets its gradient from GradientTape).  A tensor whose reference gradient is exactly zero must be exactly zero-ish:
+    its error is reported against the global scale times 1e-6."""
+    g = np.asarray(g, np.float64)
+    gref = np.asarray(gref, np.float64)
+    assert g.shape == gref.shape, (g.shape, gref.shape)
+    gmax = np.abs(gref).max() + 1e-300
+    out = OrderedDict()
+    for n, sl in tensor_slices(spec):
+        scale = np.abs(gref[sl]).max()
+        if scale < 1e-12 * gmax:
+            scale = 1e-6 * gmax
+        out[n] = float(np.abs(g[sl] - gref[sl]).max() / scale)
+    return out
+
+
+def assert_grads_per_tensor(spec, g, gref, tol, floor=None, what='gradient'):
+    """Every variable's gradient within `tol` of the reference RELATIVE TO THAT VARIABLE'S OWN largest entry:
+        max|g - gref| over the tensor  <=  tol * max|gref| over the tensor  (+ floor[tensor])
+    `floor` (absolute, one entry per trainable variable in creation order) is the noise floor of variables whose gradient is
+    analytically zero -- a bias that feeds a BatchNorm, the last BatchNorm of a mulmo encoder whose skips are unused --
+    and which therefore consist of fp32 rounding noise in ANY fp32 implementation: the golden fixtures store what plain
+    float32 numpy costs per variable (`fp32_grad_abs_err_t`) and the tests pass 10x that.  Returns {name: relative error}."""
+    g = np.asarray(g, np.float64)
+    gref = np.asarray(gref, np.float64)
+    assert g.shape == gref.shape, (g.shape, gref.shape)
+    assert np.isfinite(g).all(), what + ': non-finite entries'
+    errs, bad = OrderedDict(), []
+    for i, (n, sl) in enumerate(tensor_slices(spec)):
+        scale = np.abs(gref[sl]).max()
+        d = np.abs(g[sl] - gref[sl]).max()
+        errs[n] = float(d / (scale + 1e-300))
+        if not d <= tol * scale + (0.0 if floor is None else float(floor[i])):
+            bad.append((n, errs[n]))
+    assert not bad, '%s: %d of %d tensors off (tol %.1e): %s' % (
+        what, len(bad), len(errs), tol, ', '.join('%s %.2e' % b for b in bad[:8]))
+    return errs
+
+
+def degenerate_tensors(spec):
+    """Names of the trainable variables whose gradient is analytically (almost) zero, i.e. rounding noise in fp32:
+      * `*.tconv.bias` under bn: the transposed conv feeds a BatchNorm directly (components.py:118-120,131), which removes
+        any per-channel constant;
+      * `encoderE.downI.bn{last}.{beta,gamma}` of the mulmo encoders whose skips are unused (E != reference_index,
+        unet.py:188): the BatchNorm output only reaches max-pool -> pool BatchNorm (components.py:54,59), which commutes
+        with a per-channel shift (exactly) and positive scale (up to the BatchNorm epsilon).
+    Tests that have no float32-noise fixture (tuned vs generic at full size) judge these against the scale of a healthy
+    sibling instead (`sibling_of`)."""
+    out = set()
+    if not spec.bn:
+        return out
+    for n, _ in tensor_slices(spec):
+        if n.endswith('.tconv.bias'):
+            out.add(n)
+    if spec.arch == 'mulmo':
+        last = 'bn%d' % (spec.n_conv - 1)
+        for e in range(spec.n_encoders()):
+            if e == spec.reference_index:
+                continue
+            for i in range(spec.n_down):
+                out.add('encoder%d.down%d.%s.beta' % (e, i, last))
+                out.add('encoder%d.down%d.%s.gamma' % (e, i, last))
+    return out
+
+
+def sibling_of(name):
+    """a healthy variable fed by the same upstream gradient as the degenerate variable `name`"""
+    if name.endswith('.tconv.bias'):
+        return name[:-len('bias')] + 'kernel'
+    head, _ = name.rsplit('.', 1)                 # encoderE.downI.bnJ
+    block, bn = head.rsplit('.', 1)
+    return '%s.conv%s.bias' % (block, bn[2:])
+
+
+def assert_grads_per_tensor_nofixture(spec, g, gref, tol, degenerate_tol=None, what='gradient'):
+    """assert_grads_per_tensor for comparisons without a float32-noise fixture: degenerate variables (see
+    degenerate_tensors) are measured against their sibling's scale with `degenerate_tol` (default: tol)."""
+    g = np.asarray(g, np.float64)
+    gref = np.asarray(gref, np.float64)
+    sl = dict(tensor_slices(spec))
+    deg = degenerate_tensors(spec)
+    floor = [((degenerate_tol or tol) * np.abs(gref[sl[sibling_of(n)]]).max() if n in deg else 0.0) for n in sl]
+    return assert_grads_per_tensor(spec, g, gref, tol, floor=floor, what=what)

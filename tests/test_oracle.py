@@ -19,12 +19,13 @@ def test_oracle_reproduces_golden(name):
     assert abs(loss - float(z['loss_train'])) < 1e-9
     assert np.abs(logits - z['logits_train']).max() < 1e-5
     g = O.flatten(spec, grads)
-    if 'grads' in z.files:
-        assert Hp.rel_err(g, z['grads']) < 1e-5
+    # every variable on its own scale; the fixture stores float32 (6e-8 relative), analytically-zero variables are 1e-17
+    # noise in float64 and are held to the float32 rounding of the fixture's storage of that noise
+    Hp.assert_grads_per_tensor(spec, g, z['grads'], 1e-6, floor=[1e-12] * len(Hp.tensor_slices(spec)))
+    norms = np.array([np.sqrt((g[sl] ** 2).sum()) for _, sl in Hp.tensor_slices(spec)])
+    assert np.allclose(norms, z['grad_norms'], rtol=1e-9, atol=1e-15)
+    if 'params_after' in z.files:
         assert np.abs(O.flatten(spec, new_params) - z['params_after']).max() < 1e-6
-    else:
-        st = int(z['sample_stride'])
-        assert Hp.rel_err(g[::st], z['grads_sample']) < 1e-5
     prob, logits_eval = O.predict(spec, params, x)
     assert np.abs(logits_eval - z['logits_eval']).max() < 1e-5
     assert np.array_equal(prob > 0.5, z['mask05'])

@@ -28,7 +28,10 @@ def run(force):
     losses = [float(m.train_step(x, y, 1e-3, m.loss_cfg(weight_mul=3.0)).loss) for _ in range(3)]
     m.comm_average_state()
     red = m.comm_allreduce([1.5, -2.0], op='max').tolist()
-    out = dict(losses=losses, params=m.get_params(), state=m.get_state(), grads=m.get_grads(), red=red)
+    # metric counts of a 150-threshold AUC (600 counters, more than one staging chunk would be 2050) and counts beyond 2^24
+    big = np.arange(5000, dtype=np.float64) * 7.0 + 2.0 ** 40 + 1.0
+    red_big = bool(np.array_equal(m.comm_allreduce(big), big))
+    out = dict(losses=losses, params=m.get_params(), state=m.get_state(), grads=m.get_grads(), red=red, red_big=red_big)
     m.close()
     return out
 
@@ -39,7 +42,7 @@ def main():
     c = run(False)       # run-to-run noise floor (weight gradients are accumulated with float atomics)
     diff = {k: float(np.abs(a[k] - b[k]).max() / (np.abs(a[k]).max() + 1e-30)) for k in ('params', 'state', 'grads')}
     noise = {k: float(np.abs(a[k] - c[k]).max() / (np.abs(a[k]).max() + 1e-30)) for k in ('params', 'state', 'grads')}
-    print(json.dumps(dict(diff=diff, noise=noise, losses_plain=a['losses'], losses_rccl=b['losses'], red=b['red'])))
+    print(json.dumps(dict(diff=diff, noise=noise, losses_plain=a['losses'], losses_rccl=b['losses'], red=b['red'], red_big=b['red_big'])))
 
 
 if __name__ == '__main__':
