@@ -41,27 +41,42 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(sample_steps=6):
-    """The numpy oracle (a port: TensorFlow, the reference's CPU back-end, is not installed anywhere) timed on this
-    host on a bounded sample of the same workload: `sample_steps` train steps of one 8-slice batch."""
+CPU_THREADS = 16               # the GPU box gives one GPU's job 16 host cores; numpy's BLAS pool is pinned to that many
+
+
+def cpu_baseline(sample_steps=5):
+    """The numpy oracle (a port: TensorFlow, the reference's CPU back-end, is not installed anywhere) timed on this host on a
+    bounded sample of the same workload: `sample_steps` train steps of one 8-slice batch (C2) and of one 1-slice batch (C1,
+    BASELINE.md's CPU-baseline plan).  The BLAS / OpenMP pools are limited to CPU_THREADS threads and that number is what
+    `cores` reports; the rest of numpy (elementwise passes, im2col copies) is single-threaded."""
     from oracle import unet_oracle as O
-    spec = O.ModelSpec('unet', C, **UNET_YAML)
-    params = O.init_params(spec, seed=2)
-    x, y = synthetic_batch(BATCH_PER_GPU, H, W, C)
-    m, v = {}, {}
-    O.train_step(spec, params, m, v, 1, x[:1], y[:1], 1e-3, dict(weight_mul=3.0))      # page in / warm BLAS
-    t0 = time.time()
-    for t in range(sample_steps):
-        _, params, _, _ = O.train_step(spec, params, m, v, t + 1, x, y, 1e-3, dict(weight_mul=3.0))
-    dt = time.time() - t0
+    spec = O.ModelSpec('unet', 1, **UNET_YAML)
+    x, y = synthetic_batch(8, H, W, 1)
+    cfg = dict(weight_mul=3.0)
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=CPU_THREADS)
+        threads = CPU_THREADS
     except Exception:
-        threads = 1
-    return {'value': round(sample_steps * BATCH_PER_GPU / dt, 3), 'unit': 'slices/s', 'cores': int(threads), 'kind': 'port',
-            'sample': '%d train steps of one %dx%dx%dx%d batch (numpy oracle, fp32; host has %d cores)' % (
-                sample_steps, BATCH_PER_GPU, H, W, C, os.cpu_count())}
+        limiter, threads = None, 1
+
+    def timed(batch, steps):
+        params = O.init_params(spec, seed=2)
+        m, v = {}, {}
+        O.train_step(spec, params, m, v, 1, x[:1], y[:1], 1e-3, cfg)      # page in / warm BLAS
+        t0 = time.time()
+        for t in range(steps):
+            _, params, _, _ = O.train_step(spec, params, m, v, t + 1, x[:batch], y[:batch], 1e-3, cfg)
+        return steps * batch / (time.time() - t0)
+
+    c2 = timed(8, sample_steps)
+    c1 = timed(1, 2 * sample_steps)
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, 'restore_original_limits') else None
+    return {'value': round(c2, 3), 'unit': 'slices/s', 'cores': int(threads), 'kind': 'port',
+            'sample': '%d train steps of one 8x%dx%dx1 batch (C2) -- numpy oracle, fp32, BLAS pool limited to %d threads on a host '
+                      'with %d cores; TensorFlow (the reference CPU path) is not installed' % (sample_steps, H, W, threads, os.cpu_count()),
+            'c1_batch1': {'value': round(c1, 3), 'unit': 'slices/s', 'sample': '%d train steps of one 1x%dx%dx1 batch (C1)' % (2 * sample_steps, H, W)}}
 
 
 def main():
@@ -107,13 +122,15 @@ def main():
     # which kernel dominates?  two fully instrumented steps outside the timed region
     model.profile_reset()
     model.profile_enable(1)
-    for _ in range(2):
+    PROF_STEPS = 5
+    for _ in range(PROF_STEPS):
         model.train_step_dev(xb, yb, BATCH_PER_GPU, lr, cfg)
     model.sync()
+    full_table = list(model.profile())
     # (only kernels that move data or compute: under a profiler the bracket of a bookkeeping launch can absorb one-off costs)
     table = sorted((r for r in model.profile() if r[3] > 0 or r[4] > 0), key=lambda r: -r[2])
     dominant = table[0][0]
-    dominant_per_step = table[0][1] / 2.0          # launches of the dominant kernel per step
+    dominant_per_step = table[0][1] / float(PROF_STEPS)          # launches of the dominant kernel per step
     model.profile_enable(0)
     model.profile_reset()
     # HIP events around the dominant kernel only, on the launch stream, in every 4th step of the timed region (a bracket
@@ -138,13 +155,32 @@ def main():
         value = world * BATCH_PER_GPU * args.steps / elapsed
         name, launches, total_ms, bytes_per, flops_per = prof.get(dominant, table[0])      # (table[0]: the two instrumented steps)
         avg_ms = total_ms / max(launches, 1)
+        mfma_peak = 2500.0 if wl['dtype'] == 'bf16' else 157.3        # TFLOP/s dense, MI355X_MICROARCH.md:42-43
         if args.workload == 'unet':          # HBM-bound (AI ~ 9 FLOP/B): algorithmic bytes of the launch / its duration
             bound, unit, peak = 'hbm', 'GB/s', HBM_PEAK_GBS
             achieved = bytes_per / (avg_ms * 1e-3) / 1e9
         else:                                 # dense contractions: algorithmic FLOPs / duration against the MFMA peak
-            bound, unit = 'mfma', 'TFLOP/s'
-            peak = 2500.0 if wl['dtype'] == 'bf16' else 157.3        # MI355X_MICROARCH.md:42-43 (dense)
+            bound, unit, peak = 'mfma', 'TFLOP/s', mfma_peak
             achieved = flops_per / (avg_ms * 1e-3) / 1e12
+        # every kernel of the step (north_star: "achieved fraction of HBM/MFMA roofline reported per kernel"), from the
+        # PROF_STEPS fully bracketed steps before the timed region (a HIP-event bracket adds ~3 us of dispatch to a launch,
+        # so the short kernels read low here; the rocprofv3 summary under profiles/ has the un-bracketed durations).
+        # Each kernel is priced against the roofline that bounds it: HBM when its arithmetic intensity is below the ridge.
+        ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        roofline_all, step_bytes, step_flops = [], 0.0, 0.0
+        for kname, klaunch, kms, kbytes, kflops in sorted(full_table, key=lambda r: -r[2]):
+            if klaunch == 0:
+                continue
+            us = 1e3 * kms / klaunch
+            step_bytes += kbytes * klaunch / PROF_STEPS
+            step_flops += kflops * klaunch / PROF_STEPS
+            hbm = kbytes <= 0 or kflops / max(kbytes, 1.0) < ridge
+            ach = (kbytes / (us * 1e-6) / 1e9) if hbm else (kflops / (us * 1e-6) / 1e12)
+            roofline_all.append({'kernel': kname, 'launches_per_step': round(klaunch / PROF_STEPS, 2), 'avg_us': round(us, 2),
+                                 'algorithmic_bytes': kbytes, 'flops': kflops, 'bound': 'hbm' if hbm else 'mfma',
+                                 'achieved': round(ach, 1), 'unit': 'GB/s' if hbm else 'TFLOP/s',
+                                 'frac': round(ach / (HBM_PEAK_GBS if hbm else mfma_peak), 4)})
+        step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
         if os.path.exists(tpath) and args.workload == 'unet':
@@ -163,6 +199,12 @@ def main():
                          'launches': int(launches), 'avg_launch_us': round(avg_ms * 1e3, 2),
                          'algorithmic_bytes_per_launch': bytes_per,
                          'share_of_step': round(avg_ms * dominant_per_step / (ms_per_step if ms_per_step > 0 else 1e9), 4)},
+            # the whole step against the HBM roofline: sum of the launches' algorithmic bytes (every tensor read
+            # once and written once per layer, backward = 2 x forward) / the measured step time
+            'roofline_step': {'bound': 'hbm', 'algorithmic_bytes': step_bytes, 'flops': step_flops, 'achieved': round(step_gbs, 1),
+                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(step_gbs / HBM_PEAK_GBS, 4),
+                              'launches_per_step': round(sum(r[1] for r in full_table) / PROF_STEPS, 1)},
+            'roofline_all': roofline_all,
             'hip_event_ms_per_step': round(ev_ms / args.steps, 4),
             'final_loss': round(float(out.loss), 6),
         }

@@ -26,7 +26,8 @@ def make_dataset(paths, options, training):
                                output_size=tuple(options.get('output_size', (256, 256) if training else (512, 512))),
                                repeat=training, drop_remainder=training,
                                augment_options=options.get('augment_options') if training else False,
-                               buffer_size=options.get('buffer_size', 0) if training else 0)
+                               buffer_size=options.get('buffer_size', 0) if training else 0,
+                               normalize_exams=bool(options.get('normalize_exams', True)) if training else False)   # data.py:68,137
     if all(p.endswith('.npz') for p in paths):
         import numpy as np
         xs, ys = zip(*((z['x'], z['y']) for z in map(np.load, paths)))

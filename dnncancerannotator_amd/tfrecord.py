@@ -248,7 +248,7 @@ class TFRecordDataset:
     device (`dnnca_augment_u8` / `dnnca_warp_f32`, engine.train)."""
 
     def __init__(self, paths, slice_types, batch_size, output_size=(512, 512), repeat=False, drop_remainder=False,
-                 augment_options=False, buffer_size=0, seed=0, **ignored):
+                 augment_options=False, buffer_size=0, seed=0, normalize_exams=False, **ignored):
         from . import augment
         self.paths = list(paths)
         self.slice_types = list(slice_types)
@@ -261,6 +261,13 @@ class TFRecordDataset:
         if self.plan is not None:
             self.output_size = self.plan.output_size
         self.buffer_size = int(buffer_size)
+        # data.py:517-525 (base_from_tfrecords, normalize=True; data_options.yaml:5 for training): the files are interleaved one
+        # slice at a time, each file's slice stream repeated for ever, so that every exam file contributes equally however many
+        # slices it holds.  (tf.data's interleave only ever opens `cycle_length` = #cores files when the streams are infinite;
+        # here the round robin runs over ALL files, which is what the option is documented to mean, data.py:81.)
+        self.normalize_exams = bool(normalize_exams)
+        if self.normalize_exams and not (self.repeat and self.plan is not None):
+            raise ValueError('normalize_exams makes an endless training stream: it needs repeat=True and augment_options')
         self.rng = np.random.default_rng(seed)
         self.element_spec = (Spec((self.batch_size,) + self.output_size + (len(self.feature_idx),), np.float32),
                              Spec((self.batch_size,) + self.output_size, np.float32))
@@ -270,14 +277,34 @@ class TFRecordDataset:
         gy, gx = (s.shape[1] - oh) // 2, (s.shape[2] - ow) // 2
         return s[:, gy:gy + oh, gx:gx + ow, :]
 
+    def _file_slices(self, path):
+        for exam in read_exams(path, self.slice_types):
+            s = exam.slices
+            s = self._centre(s, min(512, s.shape[1]), min(512, s.shape[2]))
+            for k in range(len(s)):
+                yield s[k]
+
     def _raw_slices(self):
-        """uint8 [H, W, Cs] slices in file order, centre-cropped like train_ds's base() call (512 x 512, data.py:97)."""
-        for path in self.paths:
-            for exam in read_exams(path, self.slice_types):
-                s = exam.slices
-                s = self._centre(s, min(512, s.shape[1]), min(512, s.shape[2]))
-                for k in range(len(s)):
-                    yield s[k]
+        """uint8 [H, W, Cs] slices, centre-cropped like train_ds's base() call (512 x 512, data.py:97): in file order, or --
+        normalize_exams -- one slice from each file in turn, every file restarting when it runs out (endless)."""
+        if not self.normalize_exams:
+            for path in self.paths:
+                yield from self._file_slices(path)
+            return
+        streams = [self._file_slices(p) for p in self.paths]
+        empty = set()
+        while len(empty) < len(streams):
+            for i, path in enumerate(self.paths):
+                if i in empty:
+                    continue
+                try:
+                    yield next(streams[i])
+                except StopIteration:
+                    streams[i] = self._file_slices(path)
+                    try:
+                        yield next(streams[i])
+                    except StopIteration:
+                        empty.add(i)          # a file without slices drops out of the rotation
 
     def _shuffled(self, it):
         """tf.data shuffle(buffer_size): fill a buffer, then emit a random element and replace it with the next one."""

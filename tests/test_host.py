@@ -52,6 +52,26 @@ def test_dump_options_never_overwrites(tmp_path):
     assert first == p and os.path.basename(second) == 'options_.yaml'           # dump.py:30-33
     assert load.load_config(p)['config'] == {'a': 1}
     assert load.load_config(second)['config'] == {'a': 2}
+    third = dump.dump_options(p, config={'a': 3})
+    assert os.path.basename(third) == 'options__.yaml' and load.load_config(p)['config'] == {'a': 1}
+    with pytest.raises(NotImplementedError):
+        dump.dump_options(str(tmp_path / 'run' / 'options.toml'), a=1)
+    jp = dump.dump_options(str(tmp_path / 'run' / 'o.json'), a=[1, 2])
+    assert load.load_config(jp) == {'a': [1, 2]}
+
+
+def test_dump_train_results_formats(tmp_path):
+    import pickle
+    import yaml
+
+    class H:
+        epoch, history, params, model = [0, 1], {'loss': [2.0, 1.5]}, {'epochs': 2}, object()
+    p = dump.dump_train_results(str(tmp_path / 'r' / 'results.pkl'), H())
+    assert pickle.load(open(p, 'rb')) == {'epoch': [0, 1], 'history': {'loss': [2.0, 1.5]}, 'params': {'epochs': 2}, 'model': 'object'}
+    y = dump.dump_train_results(str(tmp_path / 'r' / 'results.yaml'), H(), format_='YAML')
+    assert yaml.safe_load(open(y))['history'] == {'loss': [2.0, 1.5]}
+    with pytest.raises(NotImplementedError):
+        dump.dump_train_results(str(tmp_path / 'r' / 'x'), H(), format_='csv')
 
 
 def test_loss_and_model_registries():

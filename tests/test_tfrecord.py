@@ -119,3 +119,27 @@ def test_tfrecord_dataset_element_contract(tmp_path):
         list(T.read_records(str(tmp_path / 'bad.tfrecords')))
     meta = list(T.read_exams(path))
     assert meta[1].patientID == 11 and meta[1].category == 'cancer' and meta[1].slice_types == types
+
+
+def test_normalize_exams_interleaves_files_equally(tmp_path):
+    """data.py:517-525 / data_options.yaml:5: with normalize_exams every exam FILE contributes one slice in turn, restarting
+    when it runs out, so a 6-slice exam does not outweigh a 2-slice one."""
+    from dnncancerannotator_amd import tfrecord as T
+    types = ['TRA', 'label']
+    paths = []
+    for i, n in enumerate((6, 2, 3)):
+        s = np.zeros((n, 40, 40, 2), np.uint8)
+        s[..., 0] = 10 * (i + 1) + np.arange(n)[:, None, None]          # slice k of file i carries the value 10 (i + 1) + k
+        p = str(tmp_path / ('exam%d.tfrecords' % i))
+        T.write_records(p, [T.make_example(s, i, i, '/e/%d' % i, 'cancer', types)])
+        paths.append(p)
+    ds = T.TFRecordDataset(paths, types, 3, output_size=(32, 32), repeat=True, drop_remainder=True, augment_options=None,
+                           normalize_exams=True)
+    it = iter(ds)
+    seen = [int(b.raw[k, 20, 20, 0]) for b in (next(it) for _ in range(4)) for k in range(3)]
+    assert seen == [10, 20, 30, 11, 21, 31, 12, 20, 32, 13, 21, 30]       # round robin; files 1 and 2 wrap around
+    plain = T.TFRecordDataset(paths, types, 3, output_size=(32, 32), repeat=True, drop_remainder=True, augment_options=None)
+    it = iter(plain)
+    assert [int(b.raw[k, 20, 20, 0]) for b in (next(it) for _ in range(2)) for k in range(3)] == [10, 11, 12, 13, 14, 15]
+    with pytest.raises(ValueError):
+        T.TFRecordDataset(paths, types, 3, output_size=(32, 32), normalize_exams=True)       # needs the endless training stream
