@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdnnca.so')
-SOURCES = ['model.hip', 'kernels_generic.hip', 'kernels_mfma.hip', 'kernels_misc.hip', 'kernels_igemm.hip', 'kernels_first.hip', 'kernels_aug.hip', 'debug_tools.hip']
+SOURCES = ['model.hip', 'kernels_generic.hip', 'kernels_mfma.hip', 'kernels_fused.hip', 'kernels_misc.hip', 'kernels_igemm.hip', 'kernels_first.hip', 'kernels_aug.hip', 'debug_tools.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-unused-result']
 
 

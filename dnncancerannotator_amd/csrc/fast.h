@@ -12,6 +12,10 @@ unsigned long long* fast_debug_stamps(Model* m);   // tuning aid: in-kernel s_me
 // `pool`: a max-pool op fused into the conv's epilogue (fast_pool_fusable), or nullptr
 bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool);
 bool fast_pool_fusable(const Model* m, const Op& conv, const Op& pool);
+// kernels_fused.hip: a whole Downsample / Upsample block (components.py:77-81, 158-166) of configs/unet.yaml in one launch;
+// ops[oi .. oi+2] are consumed when these return true.  store_mid: also write the block's intermediate tensors (a backward pass follows)
+bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid);
+bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 // kernels_first.hip: the one-channel-input 3x3 convs (first layer of every encoder)
 bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);   // bn_next as for ig_conv_fwd

@@ -1,0 +1,657 @@
+// kernels_fused.hip -- block-fused forward kernels for configs/unet.yaml (3/6/12 channels).
+//
+// One launch per reference block instead of one per Keras layer:
+//   k_fz_down   Downsample.call (components.py:77-81):  conv3x3+act -> conv3x3+act (= skip) -> MaxPool2D([2,2], 2)
+//   k_fz_up     Upsample.call   (components.py:158-166): Conv2DTranspose(k = s = 2) -> concat([up, skip]) -> conv3x3+act -> conv3x3+act
+// The intermediate tensors of a block never come back from HBM: a block tile lives in LDS from the first layer's input to the
+// last layer's output (halo recompute: the first conv of a block is evaluated on a tile one pixel larger on every side).
+// They are still WRITTEN once (the backward pass reads conv outputs for act' and as weight-gradient operands); an inference
+// pass (`store_mid` = 0) skips those stores.  At 128^2 / 256^2 the per-layer kernels are pure latency chains (launch -> operand
+// loads -> tile loads -> MFMA -> transpose -> store, every tile of the layer resident at once): fusing a block replaces three
+// chains by one.  At 512^2 it removes the re-reads: encoder block 43 -> 31 B per pixel, decoder block 78 -> 54 B per pixel.
+//
+// The arithmetic is the pixel-group GEMM of kernels_mfma.hip (same prepared B operands, same fmaf order per output as
+// k_pgfwd: fp32 MFMA is an fmaf chain), so logits agree with the per-layer kernels to the last bit wherever the summation
+// order over K is the same (it is: K runs over (source, dy, window offset) in both).
+//
+// LDS tiles are NHWC rows: pixel p of a row sits at LEAD + p*C floats, LEAD chosen so that the tile's first IMAGE pixel is
+// 16-byte aligned in global memory (tiles are staged and stored with 16-byte vectors over the aligned superset).  Every
+// float of every tile is initialised once at kernel start (zeros) and only ever overwritten with finite values: the
+// K-padding slots of the MFMA A operand read up to 3 floats past a window and multiply them by zero B rows.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fast.h"
+#include "kernels.h"
+
+namespace dnnca {
+namespace fz {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int up4(int a) { return (a + 3) / 4 * 4; }
+
+// ---- LDS tile geometry ----------------------------------------------------------------------------------------------------
+// All tiles of one block level share G = 12/CO (pixels per GEMM row group) and RG (groups per tile row, even): a tile of C
+// channels has rows of exactly RG*G pixels = RG*G*C floats, stored back to back behind LEAD floats.  Pixel (row r, column c) sits
+// at LEAD + r*RG*G*C + c*C.  With that, group g = r*RG + gc of ANY tile starts at LEAD + g*G*C: a conv's A-operand address and its
+// output address are linear in the group index -- no per-row arithmetic, no divisions, straight-line code.  The groups past the
+// real width of a row (and past the last row, up to a whole M-tile) are computed too: they read finite junk (the next row's
+// pixels) and their outputs land in padding pixels that no real window ever covers.
+// LEAD makes the tile's first IMAGE pixel 16-byte aligned (tiles are staged / stored as 16-byte vectors over the aligned superset).
+template <int C, int G, int RG, int ROWS, int HALO>
+struct Tile {
+    static constexpr int LEAD = (4 - (HALO * C) % 4) % 4;
+    static constexpr int LS = RG * G * C;                    // floats per row; multiple of 4 (RG is even)
+    static constexpr int LS4 = LS / 4;
+    static_assert(LS % 4 == 0, "tile rows must be whole float4's");
+    // rows + what the last M-tile's junk groups read (16 groups, two rows down, one window) rounded up
+    static constexpr int N = up4(LEAD + (ROWS + 2) * LS + 20 * G * C + 16);
+    static constexpr int N4 = N / 4;
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float act(float v, float alpha) { return alpha < 0.f ? v : (v > 0.f ? v : alpha * v); }
+
+// tuning builds (DNNCA_TUNING=1 python -m dnncancerannotator_amd.build): s_memtime stamps of wave 0 of every block, first two tiles
+#ifdef DNNCA_TUNING
+__device__ unsigned long long g_fz_stamps[1024 * 2 * 8];
+__device__ __forceinline__ unsigned long long fz_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define FZ_STAMP(i)                                                                                              \
+    do {                                                                                                         \
+        if (wave == 0 && lane == 0 && it < 2 && blockIdx.x < 1024) g_fz_stamps[(blockIdx.x * 2 + it) * 8 + (i)] = fz_now(); \
+    } while (0)
+#else
+#define FZ_STAMP(i) do { } while (0)
+#endif
+
+// Staging of ROWS rows of WPX pixels (+ the alignment superset) of a dense NHWC image (C channels, width W) into an LDS tile whose
+// pixel (0, 0) is image pixel (y0 - HALO, x0 - HALO), in two halves so that the global loads of the NEXT tile fly while the matrix
+// cores work on the current one: issue() loads into registers (unconditional loads from clamped addresses: the issue phase is
+// branch-free), commit() writes them to LDS and zeroes what lies outside the image ('same' padding) from the returned bit mask.
+template <int C, int G, int RG, int ROWS, int HALO, int WPX, int LSF, int NT>
+struct Stager {
+    static constexpr int LEAD = (4 - (HALO * C) % 4) % 4;
+    static constexpr int W4 = (LEAD + WPX * C + 3) / 4;      // float4's per row that hold real pixels
+    static constexpr int LS4 = LSF / 4;
+    static_assert(W4 <= LS4 && LSF % 4 == 0, "tile row narrower than the staged width");
+    static constexpr int NPF = cdiv(ROWS * W4, NT);
+    float4 pre[NPF];
+    unsigned ok;
+    __device__ __forceinline__ void issue(const float* __restrict__ src, int b, int y0, int x0, int H, int W, int tid) {
+        const int rowlen4 = W * C / 4;
+        const int f40 = ((x0 - HALO) * C - LEAD) / 4;         // exact: the numerator is a multiple of 4 (may be negative: -4 / 4)
+        const float4* base = reinterpret_cast<const float4*>(src) + (size_t)b * H * rowlen4;
+        const int last = H * rowlen4 - 1;
+        ok = 0;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int idx = tid + k * NT;
+            const int r = idx / W4, c4 = idx - r * W4;
+            const int gy = y0 - HALO + r, g4 = f40 + c4;
+            ok |= (idx < ROWS * W4 && (unsigned)gy < (unsigned)H && (unsigned)g4 < (unsigned)rowlen4) ? (1u << k) : 0u;
+            pre[k] = base[min(max(gy * rowlen4 + g4, 0), last)];
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds, int tid) const {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int idx = tid + k * NT;
+            const int r = idx / W4, c4 = idx - r * W4;
+            if (idx < ROWS * W4) reinterpret_cast<float4*>(lds)[r * LS4 + c4] = (ok >> k) & 1u ? pre[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+};
+
+// Store the interior (rows [HALO, HALO + TH), pixels [HALO, HALO + TW)) of an LDS tile to the dense NHWC image.
+template <int C, int G, int RG, int ROWS, int HALO, int TW, int TH, int NT>
+__device__ __forceinline__ void store_interior(const float* lds, float* __restrict__ dst, int b, int y0, int x0, int H, int W, int tid) {
+    using TL = Tile<C, G, RG, ROWS, HALO>;
+    constexpr int R4 = TW * C / 4;                       // float4's per tile row (TW * C is a multiple of 4: TW is a multiple of 16)
+    constexpr int OFF = TL::LEAD + HALO * C;             // multiple of 4 by construction of LEAD
+    static_assert(OFF % 4 == 0 && (TW * C) % 4 == 0, "unaligned tile interior");
+    float* base = dst + ((size_t)b * H + y0) * W * C + (size_t)x0 * C;
+    for (int idx = tid; idx < TH * R4; idx += NT) {
+        const int r = idx / R4, c4 = idx - r * R4;
+        const float4 v = *reinterpret_cast<const float4*>(lds + (HALO + r) * TL::LS + OFF + 4 * c4);
+        *reinterpret_cast<float4*>(base + (size_t)r * W * C + 4 * c4) = v;
+    }
+}
+
+// 'same' padding for the NEXT conv: the outermost ring of a conv output tile (OROWS x OW pixels of C channels) is that conv's
+// halo; where the ring lies outside the image it must hold zeros, not conv values.  Only border tiles pay for this pass.
+// edge: bit 0 top, 1 bottom, 2 left, 3 right ring outside the image (block-uniform).
+template <int C, int G, int RG, int OROWS, int OW, int LEAD, int NT>
+__device__ __forceinline__ void zero_ring(float* t, unsigned edge, int tid) {
+    constexpr int LS = RG * G * C;
+    if (edge & 1u) for (int i = tid; i < OW * C; i += NT) t[LEAD + i] = 0.f;
+    if (edge & 2u) for (int i = tid; i < OW * C; i += NT) t[LEAD + (OROWS - 1) * LS + i] = 0.f;
+    if (edge & 4u) for (int i = tid; i < OROWS * C; i += NT) t[LEAD + (i / C) * LS + (i % C)] = 0.f;
+    if (edge & 8u) for (int i = tid; i < OROWS * C; i += NT) t[LEAD + (i / C) * LS + (OW - 1) * C + (i % C)] = 0.f;
+}
+
+// One 3x3 'same' convolution (+bias +activation) from LDS tile(s) to an LDS tile on the fp32 matrix cores (pixel-group GEMM of
+// kernels_mfma.hip: M = groups of G = 12/CO adjacent pixels, N = (dx, co) = 12, K = (source, dy, window slot)).
+//   input  : NSRC tiles (ISTRIDE floats apart) of C channels, row stride RG*G*C; input pixel (r + dy, c + kx) feeds output (r, c)
+//   output : groups [0, NMT*16) written at out[OLEAD + g*12 + n] -- the tile of the next conv (row stride RG*12)
+// Wave w owns M-tiles w, w + NW, ... (CH of them) and interleaves their MFMA chains: independent accumulators keep the matrix pipe
+// issuing back to back and put all their LDS reads in flight together.
+// MPR = 0: M-tiles run linearly over the RG-wide rows (junk groups at the row ends and after the last row included);
+// MPR > 0: the output is exactly MPR*16 groups wide (the block's last conv: TW/G = 32 groups) -- M-tile mt covers groups
+//          [(mt % MPR)*16, +16) of row mt / MPR, no junk, and the output tile's rows are MPR*16 groups long.
+template <int C, int NSRC, int CO, int RG, int OROWS, int ILEAD, int ISTRIDE, int OLEAD, int NW, int MPR>
+struct Conv3 {
+    static constexpr int G = 12 / CO, GC = G * C, WR = (G + 2) * C, SR = (WR + 3) / 4, KS = NSRC * 3 * SR, ILS = RG * GC;
+    static constexpr int NMT = MPR ? OROWS * MPR : cdiv(OROWS * RG, 16), CH = cdiv(NMT, NW);
+    static_assert(MPR == 0 || (NW % MPR == 0 && NMT % NW == 0), "row-aligned M-tiles must divide evenly over the waves");
+    static constexpr int CSTEP = MPR ? (NW / MPR) * RG * GC : NW * 16 * GC;      // A-operand float offset between a wave's chains
+
+    static __device__ __forceinline__ void run(const float* in, float* out, const float* breg, float bias, float alpha, int wave, int lane) {
+        const int m = lane & 15, q = lane >> 4, n = m;
+        // chain c works on M-tile wave + c*NW; in the last chain the waves past the region redo M-tile NMT-1 and drop the result
+        constexpr bool RAGGED = CH * NW > NMT;
+        const bool last_ok = !RAGGED || wave + (CH - 1) * NW < NMT;           // wave-uniform
+        const int g0 = MPR ? (wave / MPR) * RG + (wave % MPR) * 16 : wave * 16;          // first group of this wave's chain 0
+        const float* a0 = in + ILEAD + q + (g0 + m) * GC;
+        const float* al = RAGGED ? in + ILEAD + q + ((last_ok ? wave + (CH - 1) * NW : NMT - 1) * 16 + m) * GC : a0 + (CH - 1) * CSTEP;
+        f32x4 acc[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int k = 0; k < SR; ++k) {
+                    const float b = breg[(s * 3 + dy) * SR + k];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const float a = c < CH - 1 ? a0[s * ISTRIDE + c * CSTEP + dy * ILS + 4 * k] : al[s * ISTRIDE + dy * ILS + 4 * k];
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+                    }
+                }
+        if (n < 12) {
+            float* o0 = out + OLEAD + (wave * 16 + 4 * q) * 12 + n;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (c < CH - 1 || last_ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o0[c * (NW * 192) + r * 12] = act(acc[c][r] + bias, alpha);
+                }
+            }
+        }
+    }
+};
+
+template <int KS>
+__device__ __forceinline__ void load_breg(float (&breg)[KS], const float* __restrict__ bmat, int lane) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) breg[s] = bmat[s * 64 + lane];
+}
+// hide the origin of the operand registers from the compiler: otherwise it keeps an s_waitcnt vmcnt(0) for them inside the tile
+// loop, which (vmcnt retires in order) would also drain the loads of the tile being staged
+template <int KS>
+__device__ __forceinline__ void pin_breg(float (&breg)[KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(breg[s]));
+}
+
+// tile order: blocks b, b + 8, ... share an XCD and its L2 -- give every XCD one contiguous eighth of the tile sequence so that
+// the halo rows of vertically adjacent tiles come out of that L2
+__device__ __forceinline__ void decode_tile(int t, int ntiles, bool xcd_map, int tiles_x, int tiles_y, int TW, int TH, int& b, int& x0, int& y0) {
+    if (xcd_map) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+    const int bx = t % tiles_x, by = (t / tiles_x) % tiles_y;
+    b = t / (tiles_x * tiles_y);
+    x0 = bx * TW;
+    y0 = by * TH;
+}
+__device__ __forceinline__ unsigned tile_edge(int x0, int y0, int TW, int TH, int H, int W) {
+    return (y0 == 0 ? 1u : 0u) | (y0 + TH == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == W ? 8u : 0u);
+}
+
+constexpr int even_up(int a) { return (a + 1) / 2 * 2; }
+// pixels per row of the low-resolution tile: >= w, rows of whole float4's that also hold the lead
+constexpr int low_row_pixels(int w, int c, int lead) {
+    int n = w;
+    while ((n * c) % 4 != 0 || n * c < lead + w * c) ++n;
+    return n;
+}
+
+struct DownArgs {
+    const float* x;          // [B, H, W, CIN]
+    const float* bmat1;      // prepared B operands of conv1 / conv2 (kernels_mfma.hip k_pg_prep)
+    const float* bmat2;
+    const float* bias1;
+    const float* bias2;
+    float* y0;               // conv1 output [B, H, W, C1] (nullptr: not stored -- inference)
+    float* y1;               // conv2 output = skip [B, H, W, C1]
+    float* pool;             // [B, H/2, W/2, C1]
+    int B, H, W, tiles_x, tiles_y;
+    float alpha1, alpha2;
+};
+
+template <int CIN, int C1, int TW, int TH, int NT, int MINW>
+__global__ __launch_bounds__(NT, MINW) void k_fz_down(DownArgs p) {
+    constexpr int NW = NT / 64;
+    constexpr int G = 12 / C1, RG = even_up(cdiv(TW + 5, G)), RG2 = TW / G, MPR = RG2 / 16;
+    static_assert(RG2 % 16 == 0, "the block tile must be whole M-tiles wide");
+    using TI = Tile<CIN, G, RG, TH + 4, 2>;
+    using T1 = Tile<C1, G, RG, TH + 2, 1>;
+    using T2 = Tile<C1, G, RG2, TH, 0>;                   // exact rows: only the stores and the pool read it
+    using CV1 = Conv3<CIN, 1, C1, RG, TH + 2, TI::LEAD, 0, T1::LEAD, NW, 0>;
+    using CV2 = Conv3<C1, 1, C1, RG, TH, T1::LEAD, 0, T2::LEAD, NW, MPR>;
+    using ST = Stager<CIN, G, RG, TH + 4, 2, TW + 4, TI::LS, NT>;
+    constexpr int KS1 = CV1::KS, KS2 = CV2::KS;
+    constexpr int T2N = up4(TH * T2::LS);
+    __shared__ float4 lds4[TI::N4 + T1::N4 + T2N / 4];
+    float* tin = reinterpret_cast<float*>(lds4);
+    float* t1 = tin + TI::N;
+    float* t2 = t1 + T1::N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+
+    ST st;
+    int tile = blockIdx.x;
+    int b, x0, y0;
+    if (tile < ntiles) {      // the first tile's loads fly during the prologue
+        decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+        st.issue(p.x, b, y0, x0, p.H, p.W, tid);
+    }
+    float breg1[KS1], breg2[KS2];
+    load_breg<KS1>(breg1, p.bmat1, lane);
+    load_breg<KS2>(breg2, p.bmat2, lane);
+    const int co = (lane & 15) % C1;
+    float bias1 = p.bias1[co], bias2 = p.bias2[co];
+    for (int i = tid; i < TI::N4 + T1::N4 + T2N / 4; i += NT) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pin_breg<KS1>(breg1);
+    pin_breg<KS2>(breg2);
+    asm volatile("" : "+v"(bias1), "+v"(bias2));
+    __syncthreads();
+
+    // software pipeline: the registers hold the NEXT tile (loads issued one iteration ago) while LDS holds the current one; the
+    // commit of the next tile sits between the last conv and the stores, so that its wait for the loads (vmcnt retires in order)
+    // does not also wait for stores that were issued a moment ago
+    int cb = b, cx0 = x0, cy0 = y0;
+    if (tile < ntiles) {
+        st.commit(tin, tid);
+        tile += gridDim.x;
+        if (tile < ntiles) {
+            decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+            st.issue(p.x, b, y0, x0, p.H, p.W, tid);
+        }
+        lds_barrier();
+    } else {
+        return;
+    }
+    int it = 0;
+    (void)it;
+#pragma unroll 1
+    for (;; ++it) {
+        const unsigned edge = tile_edge(cx0, cy0, TW, TH, p.H, p.W);
+        FZ_STAMP(0);
+        // conv1 on the tile enlarged by one pixel on every side -> t1
+        CV1::run(tin, t1, breg1, bias1, p.alpha1, wave, lane);
+        lds_barrier();
+        if (edge) {            // block-uniform: border tiles only
+            zero_ring<C1, G, RG, TH + 2, TW + 2, T1::LEAD, NT>(t1, edge, tid);
+            lds_barrier();
+        }
+        FZ_STAMP(1);
+        CV2::run(t1, t2, breg2, bias2, p.alpha2, wave, lane);
+        lds_barrier();
+        FZ_STAMP(2);
+        const bool more = tile < ntiles;                  // the registers hold a tile
+        const int nb_ = b, nx0 = x0, ny0 = y0;
+        if (more) {
+            st.commit(tin, tid);                          // tin is free: conv1 is done
+            tile += gridDim.x;
+            if (tile < ntiles) {
+                decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+                st.issue(p.x, b, y0, x0, p.H, p.W, tid);
+            }
+        }
+        FZ_STAMP(3);
+        if (p.y0) store_interior<C1, G, RG, TH + 2, 1, TW, TH, NT>(t1, p.y0, cb, cy0, cx0, p.H, p.W, tid);
+        store_interior<C1, G, RG2, TH, 0, TW, TH, NT>(t2, p.y1, cb, cy0, cx0, p.H, p.W, tid);
+        {   // MaxPool2D([2,2], 2) of the tile: TH/2 rows of TW/2 pixels
+            constexpr int PR4 = (TW / 2) * C1 / 4;
+            const int Wp = p.W >> 1, Hp = p.H >> 1;
+            float* pb = p.pool + ((size_t)cb * Hp + (cy0 >> 1)) * Wp * C1 + (size_t)(cx0 >> 1) * C1;
+            for (int idx = tid; idx < (TH / 2) * PR4; idx += NT) {
+                const int r = idx / PR4, c4 = idx - r * PR4;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int f = 4 * c4 + e, pp = f / C1, c = f - pp * C1;
+                    const float* a = t2 + (2 * r) * T2::LS + T2::LEAD + (2 * pp) * C1 + c;
+                    o[e] = fmaxf(fmaxf(a[0], a[C1]), fmaxf(a[T2::LS], a[T2::LS + C1]));
+                }
+                *reinterpret_cast<float4*>(pb + (size_t)r * Wp * C1 + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        if (!more) break;
+        lds_barrier();        // t1 / t2 are overwritten by the next tile only after every store has read them; tin is complete
+        FZ_STAMP(4);
+        cb = nb_; cx0 = nx0; cy0 = ny0;
+    }
+}
+
+struct UpArgs {
+    const float* low;        // transposed conv input [B, H/2, W/2, CIN]
+    const float* skip;       // [B, H, W, F]
+    const float* wt;         // Conv2DTranspose kernel [2][2][F][CIN] and bias [F] (parameter vector)
+    const float* bt;
+    const float* bmat0;      // conv0 ([up | skip] -> F) and conv1 (F -> F) B operands
+    const float* bmat1;
+    const float* bias0;
+    const float* bias1;
+    float* up;               // transposed conv output [B, H, W, F]   (nullptr: not stored)
+    float* y0;               // conv0 output                          (nullptr: not stored)
+    float* y1;               // conv1 output
+    int B, H, W, tiles_x, tiles_y;
+    float alpha0, alpha1;
+};
+
+template <int CIN, int F, int TW, int TH, int NT, int MINW>
+__global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
+    constexpr int NW = NT / 64;
+    constexpr int G = 12 / F, RG = even_up(cdiv(TW + 5, G)), RG2 = TW / G, MPR = RG2 / 16;
+    static_assert(RG2 % 16 == 0, "the block tile must be whole M-tiles wide");
+    // the low-resolution input tile is only read by the transposed conv (vector ALU): plain rows, halo 1 (= 2 output pixels)
+    // rows of LWP pixels back to back, so that low pixel p sits at LLEAD + p*CIN: the transposed conv is a GEMM over the pixel list
+    constexpr int LW = TW / 2 + 2, LH = TH / 2 + 2, LLEAD = (4 - CIN % 4) % 4, LWP = low_row_pixels(LW, CIN, LLEAD), LLS = LWP * CIN;
+    constexpr int NMTL = cdiv(LH * LWP, 16), LN = up4(LLEAD + NMTL * 16 * CIN + 8);
+    constexpr int NB = cdiv(4 * F, 16), KT = cdiv(CIN, 4);
+    using TU = Tile<F, G, RG, TH + 4, 2>;                 // up-sampled tile and skip tile: same geometry, adjacent in LDS
+    using T1 = Tile<F, G, RG, TH + 2, 1>;
+    using T2 = Tile<F, G, RG2, TH, 0>;
+    using CV0 = Conv3<F, 2, F, RG, TH + 2, TU::LEAD, TU::N, T1::LEAD, NW, 0>;
+    using CV1 = Conv3<F, 1, F, RG, TH, T1::LEAD, 0, T2::LEAD, NW, MPR>;
+    // Stager of the low tile: a "tile" of 1-pixel groups with LLS floats per row
+    using STL = Stager<CIN, 1, 1, LH, 1, LW, LLS, NT>;
+    using STS = Stager<F, G, RG, TH + 4, 2, TW + 4, TU::LS, NT>;
+    static_assert(STL::LEAD == LLEAD, "low tile lead");
+    constexpr int KS0 = CV0::KS, KS1 = CV1::KS;
+    static_assert(TH * T2::LS <= TU::N, "t2 aliases the up-sampled tile");
+    __shared__ float4 lds4[LN / 4 + 2 * TU::N4 + T1::N4];
+    float* tlow = reinterpret_cast<float*>(lds4);
+    float* tup = tlow + LN;
+    float* tskip = tup + TU::N;
+    float* t1 = tskip + TU::N;
+    float* t2 = tup;                                      // dead by the time conv1 runs: conv0 has consumed tup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+
+    STL stl;
+    STS sts;
+    int tile = blockIdx.x;
+    int b, x0, y0;
+    if (tile < ntiles) {
+        decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+        stl.issue(p.low, b, y0 >> 1, x0 >> 1, p.H >> 1, p.W >> 1, tid);
+        sts.issue(p.skip, b, y0, x0, p.H, p.W, tid);
+    }
+    float breg0[KS0], breg1[KS1];
+    load_breg<KS0>(breg0, p.bmat0, lane);
+    load_breg<KS1>(breg1, p.bmat1, lane);
+    const int co = (lane & 15) % F;
+    float bias0 = p.bias0[co], bias1 = p.bias1[co];
+    // Conv2DTranspose(k = s = 2) as a GEMM on the matrix cores: M = low-resolution pixels, K = CIN, N = output rows (a, e, co);
+    // B[ci][(a, e, co)] = W[a][e][co][ci] straight from the parameter vector, one register per (N block, K step)
+    float tw[NB][KT], tbias[NB];
+    int toff[NB];              // where output row (a, e, co) lands relative to up-tile pixel (2 li, 2 lj); -1: padding column
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int rr = nb * 16 + (lane & 15);
+        const bool rv = rr < 4 * F;
+        const int ae = rv ? rr / F : 0, cc = rv ? rr - ae * F : 0;
+        tbias[nb] = rv ? p.bt[cc] : 0.f;
+        toff[nb] = rv ? (ae >> 1) * TU::LS + (ae & 1) * F + cc : -1;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int ci = 4 * k + (lane >> 4);
+            tw[nb][k] = (rv && ci < CIN) ? p.wt[rr * CIN + ci] : 0.f;
+        }
+    }
+
+    for (int i = tid; i < LN / 4 + 2 * TU::N4 + T1::N4; i += NT) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pin_breg<KS0>(breg0);
+    pin_breg<KS1>(breg1);
+    asm volatile("" : "+v"(bias0), "+v"(bias1));
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        asm volatile("" : "+v"(tbias[nb]));
+#pragma unroll
+        for (int k = 0; k < KT; ++k) asm volatile("" : "+v"(tw[nb][k]));
+    }
+    __syncthreads();
+
+    // software pipeline as in k_fz_down: the registers hold the next tile's low-resolution and skip inputs; they are committed
+    // right after conv0 (the last reader of tlow / tskip), before this tile's stores are issued
+    int cb = b, cx0 = x0, cy0 = y0;
+    if (tile < ntiles) {
+        stl.commit(tlow, tid);
+        sts.commit(tskip, tid);
+        tile += gridDim.x;
+        if (tile < ntiles) {
+            decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+            stl.issue(p.low, b, y0 >> 1, x0 >> 1, p.H >> 1, p.W >> 1, tid);
+            sts.issue(p.skip, b, y0, x0, p.H, p.W, tid);
+        }
+        lds_barrier();
+    } else {
+        return;
+    }
+    int it = 0;
+    (void)it;
+#pragma unroll 1
+    for (;; ++it) {
+        const unsigned edge = tile_edge(cx0, cy0, TW, TH, p.H, p.W);
+        FZ_STAMP(0);
+        // Conv2DTranspose(k = s = 2, no activation): up[2i + a][2j + e][co] = bias[co] + sum_ci low[i][j][ci] W[a][e][co][ci]
+        // for every pixel of the (TH + 4) x (TW + 4) tile, zeros outside the image
+#pragma unroll 1
+        for (int mt = wave; mt < NMTL; mt += NW) {
+            const float* ap = tlow + LLEAD + (mt * 16 + (lane & 15)) * CIN + (lane >> 4);
+            f32x4 tacc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) tacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const float av = ap[4 * k];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) tacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tw[nb][k], tacc[nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pp = mt * 16 + 4 * (lane >> 4) + r;
+                const int li = pp / LWP, lj = pp - li * LWP;
+                if (li < LH && lj < LW) {
+                    const int gi = (cy0 >> 1) - 1 + li, gj = (cx0 >> 1) - 1 + lj;
+                    const bool inside = (unsigned)gi < (unsigned)(p.H >> 1) && (unsigned)gj < (unsigned)(p.W >> 1);
+                    float* ob = tup + TU::LEAD + (2 * li) * TU::LS + (2 * lj) * F;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (toff[nb] >= 0) ob[toff[nb]] = inside ? tacc[nb][r] + tbias[nb] : 0.f;
+                }
+            }
+        }
+        lds_barrier();
+        FZ_STAMP(1);
+        // conv0 over concat([up, skip]) (components.py:164: up-sampled first) on the tile enlarged by one pixel -> t1
+        CV0::run(tup, t1, breg0, bias0, p.alpha0, wave, lane);
+        lds_barrier();                                    // tlow / tskip are free, every wave has finished reading tup
+        FZ_STAMP(2);
+        const bool more = tile < ntiles;
+        const int nb_ = b, nx0 = x0, ny0 = y0;
+        if (more) {
+            stl.commit(tlow, tid);
+            sts.commit(tskip, tid);
+            tile += gridDim.x;
+            if (tile < ntiles) {
+                decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+                stl.issue(p.low, b, y0 >> 1, x0 >> 1, p.H >> 1, p.W >> 1, tid);
+                sts.issue(p.skip, b, y0, x0, p.H, p.W, tid);
+            }
+        }
+        if (p.up) store_interior<F, G, RG, TH + 4, 2, TW, TH, NT>(tup, p.up, cb, cy0, cx0, p.H, p.W, tid);
+        if (edge) zero_ring<F, G, RG, TH + 2, TW + 2, T1::LEAD, NT>(t1, edge, tid);
+        lds_barrier();                                    // t2 (= tup) may be overwritten; the ring is in place
+        FZ_STAMP(3);
+        CV1::run(t1, t2, breg1, bias1, p.alpha1, wave, lane);
+        if (p.y0) store_interior<F, G, RG, TH + 2, 1, TW, TH, NT>(t1, p.y0, cb, cy0, cx0, p.H, p.W, tid);
+        lds_barrier();
+        FZ_STAMP(4);
+        store_interior<F, G, RG2, TH, 0, TW, TH, NT>(t2, p.y1, cb, cy0, cx0, p.H, p.W, tid);
+        if (!more) break;
+        // t2 shares its floats with tup; what it leaves in the padding pixels is finite (activations), which is all the junk
+        // groups and the K-padding of the A operand need
+        lds_barrier();
+        FZ_STAMP(5);
+        cb = nb_; cx0 = nx0; cy0 = ny0;
+    }
+}
+
+}  // namespace fz
+
+// ================================================================================================ host side
+const float* fast_conv_bmat(Model* m, const Op& o);       // kernels_mfma.hip: prepared forward B operand of a pixel-group conv
+
+static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
+
+template <typename K>
+static int fz_resident(K kernel, int nt) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nt, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 6) per_cu = 6;
+    return 256 * per_cu;
+}
+
+static bool fz_enabled() {
+    static const bool on = getenv("DNNCA_NO_FUSED") == nullptr;
+    return on;
+}
+// tuning aid: DNNCA_FZ_ONLY=down0|down1|down2|up0|up1|up2 fuses only that block (level = log2(512 / block height) at 512 x 512)
+static bool fz_selected(const char* kind, int level) {
+    const char* e = getenv("DNNCA_FZ_ONLY");
+    if (!e) return true;
+    char want[16];
+    snprintf(want, sizeof(want), "%s%d", kind, level);
+    return strcmp(e, want) == 0;
+}
+
+// ops[oi .. oi+2] = conv3x3(CIN -> C1), conv3x3(C1 -> C1), MaxPool2D(2) of one Downsample block without BatchNorm?
+// Launches the fused kernel and returns true; false: not this shape (the caller runs the layers one by one).
+bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid) {
+    if (!fz_enabled() || (m->desc.flags & 1) || m->desc.dtype != DNNCA_F32) return false;
+    if (oi + 2 >= m->ops.size()) return false;
+    Op &c1 = m->ops[oi], &c2 = m->ops[oi + 1], &pl = m->ops[oi + 2];
+    if (c1.type != OP_CONV || c2.type != OP_CONV || pl.type != OP_POOL || c1.k != 3 || c2.k != 3 || pl.k != 2) return false;
+    if (c1.inB.d.C || c2.inB.d.C || c2.inA.d.p != c1.out.d.p || pl.inA.d.p != c2.out.d.p) return false;
+    if (!dense(c1.inA.d) || !dense(c1.out.d) || !dense(c2.out.d) || !dense(pl.out.d)) return false;
+    const int CIN = c1.inA.d.C, C1 = c1.out.d.C, H = c1.out.d.H, W = c1.out.d.W;
+    if (c2.out.d.C != C1) return false;
+    if (!fz_selected("down", C1 == 3 ? 0 : (C1 == 6 ? 1 : 2))) return false;
+    const float *b1 = fast_conv_bmat(m, c1), *b2 = fast_conv_bmat(m, c2);
+    if (!b1 || !b2) return false;
+    fz::DownArgs a{};
+    a.x = c1.inA.d.p;
+    a.bmat1 = b1; a.bmat2 = b2;
+    a.bias1 = m->p + c1.b_off; a.bias2 = m->p + c2.b_off;
+    a.y0 = store_mid ? c1.out.d.p : nullptr;
+    a.y1 = c2.out.d.p;
+    a.pool = pl.out.d.p;
+    a.B = B; a.H = H; a.W = W;
+    a.alpha1 = c1.alpha; a.alpha2 = c2.alpha;
+    const double bytes = 4.0 * B * H * W * (CIN + C1 + C1 + C1 + C1 + 0.25 * C1);      // the three layers' algorithmic bytes
+    const double flops = 2.0 * B * H * W * 9.0 * (CIN * C1 + C1 * C1);
+#define X(cin, c1v, tw, th, nt, mw)                                                                                     \
+    if (CIN == cin && C1 == c1v && W % tw == 0 && H % th == 0) {                                                  \
+        a.tiles_x = W / tw; a.tiles_y = H / th;                                                                   \
+        const int ntiles = a.tiles_x * a.tiles_y * B;                                                             \
+        static const int fit = fz_resident(fz::k_fz_down<cin, c1v, tw, th, nt, mw>, nt);                            \
+        const int g = ntiles < fit ? ntiles : fit;                                                                \
+        LAUNCH(m, "fz_down_" #cin "_" #c1v, bytes, flops,                                                         \
+               hipLaunchKernelGGL((fz::k_fz_down<cin, c1v, tw, th, nt, mw>), dim3(g), dim3(nt), 0, m->stream, a));   \
+        return true;                                                                                              \
+    }
+    static const int alt = getenv("DNNCA_FZ_NT") ? atoi(getenv("DNNCA_FZ_NT")) : 0;      // tuning aid
+    if (alt == 256) {
+        X(1, 3, 128, 8, 256, 2) X(3, 6, 64, 8, 256, 2) X(6, 12, 32, 8, 256, 2)
+    }
+    X(1, 3, 128, 8, 512, 4) X(3, 6, 64, 8, 512, 4) X(6, 12, 32, 8, 512, 4)
+#undef X
+    return false;
+}
+
+// ops[oi .. oi+2] = Conv2DTranspose(CIN -> F, 2x2/2), conv3x3([up | skip] -> F), conv3x3(F -> F) of one Upsample block without BatchNorm?
+bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid) {
+    if (!fz_enabled() || (m->desc.flags & 1) || m->desc.dtype != DNNCA_F32) return false;
+    if (oi + 2 >= m->ops.size()) return false;
+    Op &tc = m->ops[oi], &c0 = m->ops[oi + 1], &c1 = m->ops[oi + 2];
+    if (tc.type != OP_TCONV || c0.type != OP_CONV || c1.type != OP_CONV || tc.k != 2 || c0.k != 3 || c1.k != 3) return false;
+    if (c0.inA.d.p != tc.out.d.p || !c0.inB.d.C || c1.inB.d.C || c1.inA.d.p != c0.out.d.p) return false;
+    if (!dense(tc.inA.d) || !dense(tc.out.d) || !dense(c0.inB.d) || !dense(c0.out.d) || !dense(c1.out.d)) return false;
+    const int CIN = tc.inA.d.C, F = tc.out.d.C, H = tc.out.d.H, W = tc.out.d.W;
+    if (c0.inB.d.C != F || c0.out.d.C != F || c1.out.d.C != F || c0.inB.d.H != H || c0.inB.d.W != W) return false;
+    if (!fz_selected("up", F == 3 ? 0 : (F == 6 ? 1 : 2))) return false;
+    // measured on MI355X (tools/fz_ab.py, profiles/r02_fused_ab.txt): the fused decoder block beats its three per-layer launches
+    // only at 128^2 (12 channels); at 256^2 / 512^2 the block is bound by the fp32 matrix pipe (two 3x3 convs on a halo-enlarged
+    // tile) and the per-layer kernels, which overlap it better with their memory traffic, stay ahead.  DNNCA_FZ_ALL=1 fuses all.
+    static const bool all = getenv("DNNCA_FZ_ALL") != nullptr || getenv("DNNCA_FZ_ONLY") != nullptr;
+    if (!all && F != 12) return false;
+    const float *b0 = fast_conv_bmat(m, c0), *b1 = fast_conv_bmat(m, c1);
+    if (!b0 || !b1) return false;
+    fz::UpArgs a{};
+    a.low = tc.inA.d.p; a.skip = c0.inB.d.p;
+    a.wt = m->p + tc.w_off; a.bt = m->p + tc.b_off;
+    a.bmat0 = b0; a.bmat1 = b1;
+    a.bias0 = m->p + c0.b_off; a.bias1 = m->p + c1.b_off;
+    a.up = store_mid ? tc.out.d.p : nullptr;
+    a.y0 = store_mid ? c0.out.d.p : nullptr;
+    a.y1 = c1.out.d.p;
+    a.B = B; a.H = H; a.W = W;
+    a.alpha0 = c0.alpha; a.alpha1 = c1.alpha;
+    const double bytes = 4.0 * B * H * W * (0.25 * CIN + F + 2 * F + F + F + F);        // tconv (in + out) + conv0 (2 in + out) + conv1 (in + out)
+    const double flops = 2.0 * B * H * W * (F * CIN + 9.0 * (2 * F * F + F * F));
+#define X(cin, f, tw, th, nt, mw)                                                                                       \
+    if (CIN == cin && F == f && W % tw == 0 && H % th == 0) {                                                     \
+        a.tiles_x = W / tw; a.tiles_y = H / th;                                                                   \
+        const int ntiles = a.tiles_x * a.tiles_y * B;                                                             \
+        static const int fit = fz_resident(fz::k_fz_up<cin, f, tw, th, nt, mw>, nt);                                \
+        const int g = ntiles < fit ? ntiles : fit;                                                                \
+        LAUNCH(m, "fz_up_" #cin "_" #f, bytes, flops,                                                             \
+               hipLaunchKernelGGL((fz::k_fz_up<cin, f, tw, th, nt, mw>), dim3(g), dim3(nt), 0, m->stream, a));       \
+        return true;                                                                                              \
+    }
+    static const int alt = getenv("DNNCA_FZ_NT") ? atoi(getenv("DNNCA_FZ_NT")) : 0;      // tuning aid
+    if (alt == 256) {
+        X(12, 12, 32, 8, 256, 2) X(12, 6, 64, 8, 256, 2) X(6, 3, 128, 8, 256, 2)
+    }
+    X(12, 12, 32, 8, 512, 2) X(12, 6, 64, 8, 512, 2) X(6, 3, 128, 8, 512, 4)
+#undef X
+    return false;
+}
+
+}  // namespace dnnca
+
+// development aid (not part of include/dnnca.h): the stamps of the last fused kernel of a tuning build
+extern "C" int dnnca_debug_fz_stamps(unsigned long long* out, int n) {
+#ifdef DNNCA_TUNING
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dnnca::fz::g_fz_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+#else
+    (void)out; (void)n;
+    return -2;
+#endif
+}

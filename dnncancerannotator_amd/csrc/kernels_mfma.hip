@@ -935,6 +935,14 @@ static int build_plan(Model* m, PgPlan& pl) {
     return DNNCA_OK;
 }
 
+// the prepared forward B operand of a pixel-group conv (for the block-fused kernels of kernels_fused.hip); nullptr: not planned
+const float* fast_conv_bmat(Model* m, const Op& o) {
+    if (!conv_supported(m, o)) return nullptr;
+    PgPlan& pl = g_plans[m];
+    auto it = pl.slot.find({&o, 0});
+    return it == pl.slot.end() ? nullptr : pl.bmat + it->second;
+}
+
 // Called by model.hip at the top of every forward: (re)derive the B operands from the current weights.
 int fast_prepare(Model* m) {
     if (m->desc.flags & 1) return DNNCA_OK;

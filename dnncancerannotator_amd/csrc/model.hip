@@ -392,6 +392,10 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 int Cin = o.inA.d.C + o.inB.d.C;
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d) + nelem(B, o.out.d));
                 double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
+                if (!generic && fused_down_fwd(this, B, oi, training)) {      // conv, conv, pool of one encoder block in one launch
+                    oi += 2;
+                    break;
+                }
                 Op* pool = (!generic && oi + 1 < ops.size() && fast_pool_fusable(this, o, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
                 if (!generic && fast_conv_fwd(this, B, o, bytes + (pool ? 4.0 * nelem(B, pool->out.d) : 0.0), flops, pool)) {
                     pool_done = pool;
@@ -437,6 +441,10 @@ int Model::forward(const float* x_dev, int B, bool training) {
             case OP_TCONV: {
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
                 double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
+                if (!generic && fused_up_fwd(this, B, oi, training)) {        // tconv, conv, conv of one decoder block in one launch
+                    oi += 2;
+                    break;
+                }
                 Op* bn_next = (training && oi + 1 < ops.size() && ops[oi + 1].type == OP_BN && ops[oi + 1].inA.d.p == o.out.d.p &&
                                fast_bn_supported(this, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
                 if (!generic && (fast_tconv_fwd(this, B, o, bytes, flops) || ig_tconv_fwd(this, B, o, bytes, flops, bn_next))) break;
