@@ -96,6 +96,7 @@ SIGNATURES = {
     'dnnca_comm_unique_id': (C.c_int, [_VP]),
     'dnnca_comm_init': (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_size_t]),
     'dnnca_comm_world': (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'dnnca_comm_collectives': (C.c_int, [_VP, C.POINTER(C.c_int)]),
     'dnnca_comm_broadcast_weights': (C.c_int, [_VP, C.c_int]),
     'dnnca_comm_average_state': (C.c_int, [_VP]),
     'dnnca_comm_allreduce_host': (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int64, C.c_int]),

@@ -99,6 +99,18 @@ struct Model {
     // data parallel
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    // Gradient vectors above 1 MB (unet_big: 63 MB, mulmo_unet: 6.9 MB) are all-reduced in buckets while the backward pass is
+    // still running: the backward pass finalises the flat gradient vector from its END (head, decoder ... first encoder), so
+    // a bucket is the newest finalised suffix; it goes to RCCL on a second stream behind an event.  Sums over ranks are
+    // elementwise, so the result is bit-identical to the single call.
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_bucket = nullptr, ev_comm_done = nullptr;
+    int bucket_state = 0;                // 0 undecided, 1 the op order finalises a suffix (bucketing possible), -1 it does not
+    bool bucketing = false;              // this step's backward pass sends buckets
+    int64_t bucket_hi = 0, bucket_fin = 0;   // [bucket_fin, bucket_hi) is final and not yet sent
+    size_t bucket_bytes = 8u << 20;
+    int collectives_last_step = 0;       // gradient all-reduce calls issued by the last train step
+    int send_bucket(int64_t lo, int64_t hi);
     // measurement
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int prof_mode = 0;                   // 0 off, 1 every launch, 2 only `focus`, 3 every launch keyed by kernel@layer

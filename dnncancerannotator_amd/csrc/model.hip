@@ -41,6 +41,9 @@ Model::~Model() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (comm) ncclCommDestroy(comm);
+    if (ev_bucket) (void)hipEventDestroy(ev_bucket);
+    if (ev_comm_done) (void)hipEventDestroy(ev_comm_done);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -513,9 +516,41 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
     if (backward) {
         cur_op = nullptr;
         DN_TRY(ig_begin_backward(this));
+        // bucketed gradient all-reduce (data parallel, large models): see model.h.  Not for the pixel-group plan (its slabs are
+        // folded into the gradient vector by the launch that ENDS the backward pass; 34.7 KB anyway) and not with an L2
+        // regulariser (its gradient is added after the loop).
+        bucketing = false;
+        collectives_last_step = 0;
+        if (comm && !dry && (size_t)nT * 4 > (1u << 20) && desc.l2 == 0.f && !head_defer_ok) {
+            if (bucket_state == 0) {
+                int64_t prev = -1;
+                bucket_state = 1;
+                for (const Op& q : ops) {
+                    int64_t lo = q.w_off >= 0 ? q.w_off : q.b_off;
+                    if (q.b_off >= 0 && q.b_off < lo) lo = q.b_off;
+                    if (lo < 0) continue;
+                    if (lo <= prev) { bucket_state = -1; break; }
+                    prev = lo;
+                }
+                if (const char* e = getenv("DNNCA_BUCKET_BYTES")) bucket_bytes = (size_t)atol(e) > 4096 ? (size_t)atol(e) : 4096;
+            }
+            bucketing = bucket_state == 1;
+            bucket_hi = bucket_fin = nT;
+        }
         for (int i = (int)ops.size() - 1; i >= 0; --i) {
             Op& o = ops[i];
             cur_op = &o.name;
+            if (bucketing && i + 1 < (int)ops.size()) {
+                // everything from the previous (later) op's parameters to the end of the vector is final now
+                const Op& d = ops[i + 1];
+                int64_t lo = d.w_off >= 0 ? d.w_off : d.b_off;
+                if (d.b_off >= 0 && d.b_off < lo) lo = d.b_off;
+                if (lo >= 0 && lo < bucket_fin) bucket_fin = lo;
+                if ((size_t)(bucket_hi - bucket_fin) * 4 >= bucket_bytes) {
+                    DN_TRY(send_bucket(bucket_fin, bucket_hi));
+                    bucket_hi = bucket_fin;
+                }
+            }
             switch (o.type) {
                 case OP_HEAD: {
                     if (head_done) break;
@@ -609,13 +644,39 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
     return DNNCA_OK;
 }
 
+// [lo, hi) of the flat gradient vector is final on `stream`: sum it over the ranks on the communication stream
+int Model::send_bucket(int64_t lo, int64_t hi) {
+    if (hi <= lo) return DNNCA_OK;
+    if (!comm_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_bucket, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_comm_done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(ev_bucket, stream));
+    HIP_TRY(hipStreamWaitEvent(comm_stream, ev_bucket, 0));
+    ncclResult_t r = ncclAllReduce(g + lo, g + lo, (size_t)(hi - lo), ncclFloat, ncclSum, comm, comm_stream);
+    if (r != ncclSuccess) { set_error("ncclAllReduce(bucket): %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
+    ++collectives_last_step;
+    return DNNCA_OK;
+}
+
 int Model::optimizer_step(float lr) {
     cur_op = nullptr;
     float gscale = 1.0f;
-    if (comm && !dry) {
+    if (comm && !dry && bucketing) {
+        // the backward pass has sent the finalised suffix in buckets; what is left -- the first layers and the step's loss in the
+        // tail -- follows on the same (communication) stream, and Adam waits for all of it
+        bucketing = false;
+        DN_TRY(send_bucket(0, bucket_hi));
+        DN_TRY(send_bucket(nT, nT + 1));
+        HIP_TRY(hipEventRecord(ev_comm_done, comm_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, ev_comm_done, 0));
+        gscale = 1.0f / (float)world;
+    } else if (comm && !dry) {
         // one all-reduce over [gradients ..., loss]: MirroredStrategy's cross-replica sum (engine.py:262) [TF-2.6]
         ncclResult_t r = ncclAllReduce(g, g, (size_t)nT + 1, ncclFloat, ncclSum, comm, stream);
         if (r != ncclSuccess) { set_error("ncclAllReduce: %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
+        collectives_last_step = 1;
         gscale = 1.0f / (float)world;
     }
     iterations += dry ? 0 : 1;
@@ -940,6 +1001,13 @@ int dnnca_comm_world(void* model, int* rank, int* world) {
     MODEL(model);
     if (rank) *rank = M->rank;
     if (world) *world = M->world;
+    return DNNCA_OK;
+}
+
+int dnnca_comm_collectives(void* model, int* count) {
+    MODEL(model);
+    if (!count) return DNNCA_EINVAL;
+    *count = M->collectives_last_step;
     return DNNCA_OK;
 }
 

@@ -331,6 +331,12 @@ class DeviceModel:
     def comm_init(self, rank, world, unique_id):
         check(self.lib.dnnca_comm_init(self.handle, int(rank), int(world), unique_id, len(unique_id) if unique_id else 0))
 
+    def comm_collectives(self):
+        """gradient all-reduce calls of the last train step (> 1: bucketed)"""
+        n = C.c_int()
+        check(self.lib.dnnca_comm_collectives(self.handle, C.byref(n)))
+        return n.value
+
     def comm_broadcast_weights(self, root=0):
         check(self.lib.dnnca_comm_broadcast_weights(self.handle, int(root)))
 

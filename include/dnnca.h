@@ -169,6 +169,9 @@ int dnnca_pixel_confusion_of(void* model, const float* prob_hw, const float* y_h
 int dnnca_comm_unique_id(void* id_out /* DNNCA_UNIQUE_ID_BYTES */);
 int dnnca_comm_init(void* model, int rank, int world, const void* unique_id, size_t id_len);   /* world == 1: no-op */
 int dnnca_comm_world(void* model, int* rank, int* world);
+/* gradient all-reduce calls the last train step issued: 1, or several when a gradient vector above 1 MB was sent in buckets
+ * (reverse layer order, second stream) while the backward pass was still running -- bit-identical to the single call */
+int dnnca_comm_collectives(void* model, int* count);
 int dnnca_comm_broadcast_weights(void* model, int root);   /* weights, BN statistics and Adam slots of `root` on every rank */
 int dnnca_comm_average_state(void* model);          /* BN moving statistics: mean over ranks before a checkpoint */
 /* small host-side reductions (validation loss sums, metric counts: MirroredStrategy's metric aggregation); doubles, any length */

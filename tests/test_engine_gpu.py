@@ -433,6 +433,26 @@ def test_rccl_one_rank_rehearsal(gpu):
     assert out['red_big'] is True          # 5000 doubles > 2^40 through the chunked host all-reduce, exact
 
 
+def test_bucketed_gradient_allreduce_rehearsal(gpu):
+    """Gradient vectors above 1 MB (unet_big 63 MB, mulmo_unet 6.9 MB) are all-reduced in buckets on a second stream while
+    the backward pass runs (reverse layer order: the backward pass finalises the flat gradient vector from its end).  On a
+    one-rank communicator every sum is the identity, so training with 256 KB buckets must equal training without a
+    communicator (up to the run-to-run noise of the float atomics), and the step must really have issued several collectives."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_one_rank.py'), 'big'], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, DNNCA_BUCKET_BYTES='262144'))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['n'] * 4 > (1 << 20)
+    assert min(out['calls']) >= 5 and out['calls_plain'] == [0, 0, 0], out       # ~4 MB in 256 KB buckets + the remainder + the loss
+    assert out['diff_grads'] <= max(1e-5, 4 * out['noise_grads']), out
+    assert out['diff_params'] <= max(1e-3, 4 * out['noise_params']), out
+    np.testing.assert_allclose(out['losses_plain'], out['losses_rccl'], rtol=1e-5)
+
+
 @pytest.mark.parametrize('force_generic', [False, True])
 def test_label_smoothing_loss_matches_oracle(gpu, force_generic):
     """deploy_options.loss.config.label_smoothing (utils/losses.py:62-67): the labels are blurred on the device (filter 6, sigma 3,

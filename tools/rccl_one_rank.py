@@ -36,8 +36,36 @@ def run(force):
     return out
 
 
+def run_big(force, bucket_bytes=None):
+    """a 4 MB gradient vector (dense-channel kernels, BatchNorm): the bucketed all-reduce on the second stream"""
+    if force:
+        os.environ['DNNCA_FORCE_RCCL'] = '1'
+    else:
+        os.environ.pop('DNNCA_FORCE_RCCL', None)
+    m = dev.DeviceModel('unet', 1, 32, 32, 2, n_filters_first=32, n_downsample=3, rate=2, kernel_size=3, conv_stride=1,
+                        bn=True, padding='same')
+    m.init_glorot(seed=4)
+    m.comm_init(0, 1, dev.DeviceModel.comm_unique_id() if force else None)
+    x, y = synthetic_batch(2, 32, 32, 1)
+    losses, calls = [], []
+    for _ in range(3):
+        losses.append(float(m.train_step(x, y, 1e-3, m.loss_cfg(weight_mul=3.0)).loss))
+        calls.append(m.comm_collectives())
+    out = dict(losses=losses, calls=calls, params=m.get_params(), grads=m.get_grads(), n=int(m.n_trainable))
+    m.close()
+    return out
+
+
 def main():
     dev.init_device(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'big':
+        # DNNCA_BUCKET_BYTES is read once per process: this process runs with the value the parent chose
+        p, q, r = run_big(False), run_big(True), run_big(False)
+        rel = lambda u, v: float(np.abs(u - v).max() / (np.abs(u).max() + 1e-30))       # noqa: E731
+        print(json.dumps(dict(n=q['n'], calls=q['calls'], calls_plain=p['calls'], diff_params=rel(p['params'], q['params']),
+                              diff_grads=rel(p['grads'], q['grads']), noise_params=rel(p['params'], r['params']),
+                              noise_grads=rel(p['grads'], r['grads']), losses_plain=p['losses'], losses_rccl=q['losses'])))
+        return
     a, b = run(False), run(True)
     c = run(False)       # run-to-run noise floor (weight gradients are accumulated with float atomics)
     diff = {k: float(np.abs(a[k] - b[k]).max() / (np.abs(a[k]).max() + 1e-30)) for k in ('params', 'state', 'grads')}
