@@ -308,9 +308,32 @@ struct BW {
     static constexpr int LDS4 = STAGE4 > RED4 ? STAGE4 : RED4;
 };
 
-template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB>
-__global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
+// sum over the 64 lanes of a wave, result in lane 63 (DPP: four shifts inside the 16-lane rows, then the two row broadcasts)
+#define DNNCA_DPP_ADD(v, ctrl, rmask) \
+    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, true))
+__device__ __forceinline__ float wave_total_l63(float v) {
+    DNNCA_DPP_ADD(v, 0x118, 0xf);     // row_shr:8
+    DNNCA_DPP_ADD(v, 0x114, 0xf);     // row_shr:4
+    DNNCA_DPP_ADD(v, 0x112, 0xf);     // row_shr:2
+    DNNCA_DPP_ADD(v, 0x111, 0xf);     // row_shr:1  -> lane 15 of each row holds the row's sum
+    DNNCA_DPP_ADD(v, 0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+    DNNCA_DPP_ADD(v, 0x143, 0xc);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
+__device__ __forceinline__ int slab_index(int mrow, int n);
+
+// VW (3 -> 3 channel convs, the 512^2 level): the weight gradient leaves the matrix cores.  With 3 channels the pixel-group GEMM
+// spends 16 MFMAs per 64 pixels on it at a third of their capacity (structural zeros), as much as the whole data gradient, and the
+// fp32 matrix pipe was the co-limiter of this kernel (15 of 28 us at full issue).  As plain outer products it is 81 + 3 FMAs per
+// pixel with no waste, and the vector ALU is idle next to the matrix pipe: the block's waves SPLIT -- waves [0, NW/2) run the
+// data-gradient MFMAs for the whole tile, waves [NW/2, NW) walk down pixel columns of the same staged tiles with a sliding
+// 3 x 3 x C window in registers and keep dW[dy][kx][ci][co] + db[co] in 84 accumulators per lane.  Every SIMD hosts one wave of
+// each kind (waves are dealt to SIMDs cyclically), so the two pipes run side by side.
+template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB, bool VW = false>
+__global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs p) {
     constexpr int NW = NT / 64;
+    static_assert(!VW || (C == 3 && CO == 3 && NT == 512 && DGRAD), "VW: 3 -> 3 channels, eight waves, with data gradient");
+    constexpr int NWD = VW ? NW / 2 : NW;          // waves that run the data gradient
     using Wc = BW<C, NSRC, CO>;
     using TGg = typename Wc::TGg;
     using TGx = typename Wc::TGx;
@@ -354,7 +377,13 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
     for (int s = 0; s < NSRC; ++s)
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // VW: two sources: dW[dy][kx*3 + ci][co] (81) + db[co] (3) of this lane's pixels; one source: this wave's kernel row (27) or db
+    constexpr int NWACC = !VW ? 1 : (NSRC == 2 ? 84 : 27);
+    float wacc[NWACC];
+#pragma unroll
+    for (int i = 0; i < NWACC; ++i) wacc[i] = 0.f;
 
+    if (VW && wave < NWD) __builtin_amdgcn_s_setprio(2);     // the MFMA waves' few vector instructions go first; the FMA waves fill in
     float breg[DGRAD ? NPASS * KSd : 1];
     if (DGRAD) {
 #pragma unroll
@@ -428,17 +457,17 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
         // ---- data gradient: conv of dz with the flipped kernel; M-tiles of 16 groups x Gd pixels
         if (DGRAD && !(DBG_FLAGS(p) & 1)) {
             // M-tiles of this wave: t = wave + 4j, j < MTX*TH/4; NCH of them are processed with interleaved MFMA chains
-            constexpr int PERW = Wc::MTX * TH / NW;
+            constexpr int PERW = Wc::MTX * TH / NWD;
             constexpr int NCH = PERW >= 4 ? 4 : PERW;
 #pragma unroll 1
-            for (int j0 = 0; j0 < PERW; j0 += NCH) {
+            for (int j0 = 0; j0 < (VW && wave >= NWD ? 0 : PERW); j0 += NCH) {
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     f32x4 d[NCH];
                     int txs[NCH], tys[NCH];
 #pragma unroll
                     for (int i = 0; i < NCH; ++i) {
-                        const int t = wave + NW * (j0 + i);
+                        const int t = wave + NWD * (j0 + i);
                         txs[i] = t % Wc::MTX;
                         tys[i] = t / Wc::MTX;
                         d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -493,6 +522,81 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
             }
         }
         STAMP(3);
+        if constexpr (VW) {
+            // ---- weight gradient on the vector ALU (waves NWD .. NW-1): lane = one pixel column, sliding window down the rows
+            if (wave >= NWD) {
+                const int wv = wave - NWD;
+                if constexpr (NSRC == 1) {
+                    // one kernel row dy per wave (27 accumulators): waves 0..2 walk the whole tile, reading input row r + dy for
+                    // output row r; wave 3 sums dz (the bias gradient).  Few registers: two blocks per CU stay resident.
+#pragma unroll 1
+                    for (int h = 0; h < 2; ++h) {
+                        const int col = h * 64 + lane;                                       // TW = 128 = two wave widths
+                        const float* gb = gl + TGg::HL + col * CO + LSg;                      // dz of (row 0, col)
+                        if (wv < 3) {
+                            const float* xb = xl + TGx::LEAD + col * C + wv * LSx;           // window row dy = wv of (row 0, col)
+                            // two rows in flight: the LDS reads of the next row are issued before the 27 FMAs of this one
+                            float xr[2][9], dzv[2][3];
+                            auto load = [&](int b, int r) {
+#pragma unroll
+                                for (int j = 0; j < 9; ++j) xr[b][j] = xb[r * LSx + j];
+#pragma unroll
+                                for (int co = 0; co < 3; ++co) dzv[b][co] = gb[r * LSg + co];
+                            };
+                            auto fma27 = [&](int b) {
+#pragma unroll
+                                for (int j = 0; j < 9; ++j)
+#pragma unroll
+                                    for (int co = 0; co < 3; ++co) wacc[j * 3 + co] = fmaf(xr[b][j], dzv[b][co], wacc[j * 3 + co]);
+                            };
+                            load(0, 0);
+#pragma unroll 1
+                            for (int r = 0; r < TH; r += 2) {
+                                load(1, r + 1);
+                                fma27(0);
+                                load(0, r + 2 < TH ? r + 2 : TH - 1);
+                                fma27(1);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < TH; ++r)
+#pragma unroll
+                                for (int co = 0; co < 3; ++co) wacc[co] += gb[r * LSg + co];
+                        }
+                    }
+                } else {
+                // two sources: waves 0, 1 take the columns of source 0, waves 2, 3 those of source 1; a lane walks down its
+                // column with a sliding 3 x 3 x C window in registers (81 + 3 accumulators)
+                const int src = wv >> 1;
+                const int col = (wv & 1) * 64 + lane;                                   // TW = 128 = two wave widths
+                constexpr int ROWS = TH;
+                const int r0 = 0;
+                const float* xb = xl + src * (TGx::N4 * 4) + TGx::LEAD + col * C;      // window of pixel (row, col): 9 floats from here
+                const float* gb = gl + TGg::HL + col * CO;
+                float xw[3][9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { xw[0][j] = xb[r0 * LSx + j]; xw[1][j] = xb[(r0 + 1) * LSx + j]; }
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    const int r = r0 + rr;
+                    float dzv[3];
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) dzv[co] = gb[(r + 1) * LSg + co];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) xw[(rr + 2) % 3][j] = xb[(r + 2) * LSx + j];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int j = 0; j < 9; ++j)
+#pragma unroll
+                            for (int co = 0; co < 3; ++co)
+                                wacc[(dy * 9 + j) * 3 + co] = fmaf(xw[(rr + dy) % 3][j], dzv[co], wacc[(dy * 9 + j) * 3 + co]);
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) wacc[81 + co] += dzv[co];
+                }
+                }
+            }
+        } else {
         // ---- weight gradient: K = pixel groups (4 per MFMA); every wave takes rows ty = wave, wave + 4
 #pragma unroll 1
         for (int ty = (DBG_FLAGS(p) & 2) ? TH : wave; ty < TH; ty += NW) {
@@ -517,6 +621,7 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
                     }
             }
         }
+        }
         STAMP(4);
         if (DB) {
             if (next < ntiles) {
@@ -533,6 +638,31 @@ __global__ __launch_bounds__(NT) void k_pgbwd(BwdArgs p) {
         tile = next;
     }
 
+    if constexpr (VW) {
+        // lane sums by DPP, the block's four weight-gradient waves through LDS, then one atomic per element into slab
+        // (blockIdx % NBUCKET).  The totals go where k_pg_fold expects D[(dy, j), (dx, co)]: everything in the dx = 0 entries
+        // (j = kx*C + ci), zeros elsewhere (the slabs are zeroed at the top of the step), the bias in the all-ones row.
+        float* red = reinterpret_cast<float*>(lds4);
+        __syncthreads();                       // every wave has left the tile loop: the staged tiles are dead
+        if (wave >= NWD) {
+            const int wv = wave - NWD;
+#pragma unroll
+            for (int i = 0; i < NWACC; ++i) {
+                const float t = wave_total_l63(wacc[i]);
+                // one source: wave wv < 3 holds kernel row wv (elements wv*27 ..), wave 3 the bias (81 .. 83)
+                if (lane == 63 && (NSRC == 2 || wv < 3 || i < 3)) red[NSRC == 2 ? wv * 84 + i : wv * 27 + i] = t;
+            }
+        }
+        __syncthreads();
+        const int bucket = blockIdx.x % NBUCKET;
+        for (int i = tid; i < NSRC * 84; i += NT) {
+            const int s = i / 84, e = i - s * 84;
+            const float v = NSRC == 2 ? red[(2 * s) * 84 + e] + red[(2 * s + 1) * 84 + e] : red[e];
+            const int mrow = e < 81 ? (e / 27) * WRw + (e / 3) % 9 : 3 * WRw, co = e < 81 ? e % 3 : e - 81;
+            atomicAdd(p.slabs[s] + (size_t)bucket * (MT * 256) + slab_index(mrow, co), v);
+        }
+        return;
+    }
     // ---- sum the 4 waves through LDS; the block adds its partial D into slab (blockIdx % NBUCKET)
     float* red = reinterpret_cast<float*>(lds4);
     constexpr int PER = NSRC * MT * 256;
@@ -1060,6 +1190,25 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     const bool db = pl.double_buffer && ntiles >= 3 * nb;
     const double bytes = out_bytes + (o.need_din ? 2 : 1) * in_bytes;
     const double fl = (o.need_din ? 2 : 1) * flops;
+    // 3 -> 3 channels: the variant whose weight gradient runs on the vector ALU beside the data-gradient MFMAs
+    // (measured, profiles/r02_vw_ab.txt: two sources 52.4 -> 48.2 us; one source 31.4 -> 32.0 us -- there the matrix pipe is not
+    //  what the data-gradient waves wait for -- so the single-source conv keeps the all-MFMA kernel unless DNNCA_VW_ALL is set)
+    static const bool vw_on = getenv("DNNCA_NO_VW") == nullptr;
+    static const bool vw_all = getenv("DNNCA_VW_ALL") != nullptr;
+    if (vw_on && o.need_din && C == 3 && CO == 3 && (NS == 2 || vw_all)) {
+        if (NS == 1) {
+            static const int fit = resident_blocks(k_pgbwd<3, 1, 3, true, 512, false, true>, 1 << 20);
+            const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);
+            LAUNCH(m, "pgbwd_3x1_3", bytes, fl,
+                   hipLaunchKernelGGL((k_pgbwd<3, 1, 3, true, 512, false, true>), dim3(g), dim3(512), 0, m->stream, a));
+        } else {
+            static const int fit = resident_blocks(k_pgbwd<3, 2, 3, true, 512, false, true>, 1 << 20);
+            const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);
+            LAUNCH(m, "pgbwd_3x2_3", bytes, fl,
+                   hipLaunchKernelGGL((k_pgbwd<3, 2, 3, true, 512, false, true>), dim3(g), dim3(512), 0, m->stream, a));
+        }
+        return true;
+    }
 #define X(c, ns, co)                                                                                            \
     if (C == c && NS == ns && CO == co) {                                                                       \
         (void)db;                                                                                               \
