@@ -498,15 +498,24 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
                         __builtin_amdgcn_wave_barrier();
                         const int sp = lane / PER4, i4 = lane - sp * PER4;
                         const int src = NPASS == 2 ? ps : sp;
+                        // (the destination is picked with selects between kernel arguments: indexing p.dx / p.acc / p.mask with a
+                        //  per-lane value made the compiler FETCH them from the kernarg segment with vector loads, and the
+                        //  s_waitcnt vmcnt(0) behind each of those also drained the next tile's prefetch -- a full HBM round
+                        //  trip per M-tile, 2 400 cycles around 480 cycles of MFMAs)
+                        float* dxs;
+                        int accs, masks;
+                        if constexpr (NPASS == 2) { dxs = ps ? p.dx[1] : p.dx[0]; accs = ps ? p.acc[1] : p.acc[0]; masks = ps ? p.mask[1] : p.mask[0]; }
+                        else if constexpr (SPL == 2) { dxs = sp ? p.dx[1] : p.dx[0]; accs = sp ? p.acc[1] : p.acc[0]; masks = sp ? p.mask[1] : p.mask[0]; }
+                        else { dxs = p.dx[0]; accs = p.acc[0]; masks = p.mask[0]; }
                         const int f0 = (x0 + tx * 16 * Gd) * C + 4 * i4;        // float index within the image row
                         if (lane < SPL * PER4 && f0 < p.W * C && y < p.H) {
                             float4 v = reinterpret_cast<const float4*>(orow)[lane];
-                            float* dst = p.dx[src] + ((size_t)b * p.H + y) * p.W * C + f0;
-                            if (p.acc[src]) {
+                            float* dst = dxs + ((size_t)b * p.H + y) * p.W * C + f0;
+                            if (accs) {
                                 const float4 o = *reinterpret_cast<const float4*>(dst);
                                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                             }
-                            if (p.mask[src]) {
+                            if (masks) {
                                 const float4 xv = *reinterpret_cast<const float4*>(
                                     xl + src * (TGx::N4 * 4) + (ty + 1) * LSx + TGx::HL + tx * 16 * Gd * C + 4 * i4);
                                 v.x *= xv.x > 0.f ? 1.0f : p.alpha;
