@@ -29,6 +29,9 @@ def short_name(k):
     m = re.match(r'dnnca::k_(tconv2_fwd|tconv_bwd)<(\d+), (\d+)', k)
     if m:
         return '%s_%s_%s' % m.groups()
+    m = re.match(r'dnnca::fz::k_fz_(down|up)<(\d+), (\d+)', k)
+    if m:
+        return 'fz_%s_%s_%s' % m.groups()
     m = re.match(r'dnnca::(?:ig::|igb::|first::)?k_(\w+)', k)
     if m:
         return m.group(1)
