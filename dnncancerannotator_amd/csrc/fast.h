@@ -12,9 +12,12 @@ unsigned long long* fast_debug_stamps(Model* m);   // tuning aid: in-kernel s_me
 // `pool`: a max-pool op fused into the conv's epilogue (fast_pool_fusable), or nullptr
 bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool);
 bool fast_pool_fusable(const Model* m, const Op& conv, const Op& pool);
+// the conv that feeds the head, training step: head + loss + head backward ride in its epilogue (labels' statistics already on the stream)
+bool fast_conv_fwd_head(Model* m, int B, Op& o, Op& head, const float* y, const dnnca_loss_cfg& cfg, float gscale, double bytes, double flops);
 // kernels_fused.hip: a whole Downsample / Upsample block (components.py:77-81, 158-166) of configs/unet.yaml in one launch;
 // ops[oi .. oi+2] are consumed when these return true.  store_mid: also write the block's intermediate tensors (a backward pass follows)
-bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid);
+bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* labels = nullptr);   // labels: also reduce them (first block only)
+bool fast_head_in_conv_possible(Model* m);      // would fast_conv_fwd_head take the conv that feeds the head?
 bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 // kernels_first.hip: the one-channel-input 3x3 convs (first layer of every encoder)

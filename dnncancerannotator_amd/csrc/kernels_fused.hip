@@ -234,6 +234,10 @@ struct DownArgs {
     float* pool;             // [B, H/2, W/2, C1]
     int B, H, W, tiles_x, tiles_y;
     float alpha1, alpha2;
+    // first block of a train step: the labels [B, H, W] of every tile are read alongside (tiles partition the image) and their
+    // (sum, min, max) leave the block as one row of a partials table -- utils/losses.py:87-102 without a launch of its own
+    const float* labels;
+    float* label_part;       // [gridDim.x][4]
 };
 
 template <int CIN, int C1, int TW, int TH, int NT, int MINW>
@@ -258,10 +262,30 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_down(DownArgs p) {
     const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
 
     ST st;
+    // label statistics (first encoder block of a train step): a tile's TH x TW labels are TH*TW/4 16-byte vectors, one per thread,
+    // prefetched with the tile and folded into per-thread (sum, min, max) when the tile is committed
+    constexpr int LAB4 = TH * TW / 4;
+    static_assert(LAB4 <= NT, "one label vector per thread");
+    float4 ylab = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ysum = 0.f, ymin = INFINITY, ymax = -INFINITY;
+    auto issue_labels = [&](int bb, int yy0, int xx0) {
+        if (p.labels && tid < LAB4) {
+            const int r = tid / (TW / 4), c4 = tid - r * (TW / 4);
+            ylab = *reinterpret_cast<const float4*>(p.labels + ((size_t)bb * p.H + yy0 + r) * p.W + xx0 + 4 * c4);
+        }
+    };
+    auto fold_labels = [&]() {
+        if (p.labels && tid < LAB4) {
+            ysum += (ylab.x + ylab.y) + (ylab.z + ylab.w);
+            ymin = fminf(fminf(ymin, fminf(ylab.x, ylab.y)), fminf(ylab.z, ylab.w));
+            ymax = fmaxf(fmaxf(ymax, fmaxf(ylab.x, ylab.y)), fmaxf(ylab.z, ylab.w));
+        }
+    };
     int tile = blockIdx.x;
     int b, x0, y0;
     if (tile < ntiles) {      // the first tile's loads fly during the prologue
         decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+        issue_labels(b, y0, x0);
         st.issue(p.x, b, y0, x0, p.H, p.W, tid);
     }
     float breg1[KS1], breg2[KS2];
@@ -282,19 +306,19 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_down(DownArgs p) {
     int cb = b, cx0 = x0, cy0 = y0;
     if (tile < ntiles) {
         st.commit(tin, tid);
+        fold_labels();
         tile += gridDim.x;
         if (tile < ntiles) {
             decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+            issue_labels(b, y0, x0);
             st.issue(p.x, b, y0, x0, p.H, p.W, tid);
         }
         lds_barrier();
-    } else {
-        return;
     }
     int it = 0;
     (void)it;
 #pragma unroll 1
-    for (;; ++it) {
+    for (; blockIdx.x < (unsigned)ntiles; ++it) {
         const unsigned edge = tile_edge(cx0, cy0, TW, TH, p.H, p.W);
         FZ_STAMP(0);
         // conv1 on the tile enlarged by one pixel on every side -> t1
@@ -312,9 +336,11 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_down(DownArgs p) {
         const int nb_ = b, nx0 = x0, ny0 = y0;
         if (more) {
             st.commit(tin, tid);                          // tin is free: conv1 is done
+            fold_labels();
             tile += gridDim.x;
             if (tile < ntiles) {
                 decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
+                issue_labels(b, y0, x0);
                 st.issue(p.x, b, y0, x0, p.H, p.W, tid);
             }
         }
@@ -341,6 +367,22 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_down(DownArgs p) {
         lds_barrier();        // t1 / t2 are overwritten by the next tile only after every store has read them; tin is complete
         FZ_STAMP(4);
         cb = nb_; cx0 = nx0; cy0 = ny0;
+    }
+    if (p.labels) {           // block partials of the label statistics: wave shuffles, the waves through LDS, one table row
+        for (int o = 32; o > 0; o >>= 1) {
+            ysum += __shfl_down(ysum, o, 64);
+            ymin = fminf(ymin, __shfl_down(ymin, o, 64));
+            ymax = fmaxf(ymax, __shfl_down(ymax, o, 64));
+        }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds4);
+        if (lane == 0) { red[wave] = ysum; red[NW + wave] = ymin; red[2 * NW + wave] = ymax; }
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f, mn = INFINITY, mx = -INFINITY;
+            for (int w = 0; w < NW; ++w) { s += red[w]; mn = fminf(mn, red[NW + w]); mx = fmaxf(mx, red[2 * NW + w]); }
+            reinterpret_cast<float4*>(p.label_part)[blockIdx.x] = make_float4(s, mn, mx, 0.f);
+        }
     }
 }
 
@@ -552,7 +594,7 @@ static bool fz_selected(const char* kind, int level) {
 
 // ops[oi .. oi+2] = conv3x3(CIN -> C1), conv3x3(C1 -> C1), MaxPool2D(2) of one Downsample block without BatchNorm?
 // Launches the fused kernel and returns true; false: not this shape (the caller runs the layers one by one).
-bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid) {
+bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* labels) {
     if (!fz_enabled() || (m->desc.flags & 1) || m->desc.dtype != DNNCA_F32) return false;
     if (oi + 2 >= m->ops.size()) return false;
     Op &c1 = m->ops[oi], &c2 = m->ops[oi + 1], &pl = m->ops[oi + 2];
@@ -573,7 +615,13 @@ bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid) {
     a.pool = pl.out.d.p;
     a.B = B; a.H = H; a.W = W;
     a.alpha1 = c1.alpha; a.alpha2 = c2.alpha;
-    const double bytes = 4.0 * B * H * W * (CIN + C1 + C1 + C1 + C1 + 0.25 * C1);      // the three layers' algorithmic bytes
+    if (labels) {         // the caller (forward of a train step) wants this step's label statistics from this launch
+        m->label_part_valid = false;
+        if (!m->label_part && m->alloc((void**)&m->label_part, 2048 * 16) != DNNCA_OK) return false;
+        a.labels = labels;
+        a.label_part = m->label_part;
+    }
+    const double bytes = 4.0 * B * H * W * (CIN + C1 + C1 + C1 + C1 + 0.25 * C1 + (labels ? 1 : 0));      // the three layers' algorithmic bytes
     const double flops = 2.0 * B * H * W * 9.0 * (CIN * C1 + C1 * C1);
 #define X(cin, c1v, tw, th, nt, mw)                                                                                     \
     if (CIN == cin && C1 == c1v && W % tw == 0 && H % th == 0) {                                                  \
@@ -581,8 +629,10 @@ bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid) {
         const int ntiles = a.tiles_x * a.tiles_y * B;                                                             \
         static const int fit = fz_resident(fz::k_fz_down<cin, c1v, tw, th, nt, mw>, nt);                            \
         const int g = ntiles < fit ? ntiles : fit;                                                                \
+        if (labels && (g > 2048 || W != c1.out.d.W)) return false;                                                \
         LAUNCH(m, "fz_down_" #cin "_" #c1v, bytes, flops,                                                         \
                hipLaunchKernelGGL((fz::k_fz_down<cin, c1v, tw, th, nt, mw>), dim3(g), dim3(nt), 0, m->stream, a));   \
+        if (labels) { m->label_part_valid = true; m->label_part_nblk = g; }                                       \
         return true;                                                                                              \
     }
     static const int alt = getenv("DNNCA_FZ_NT") ? atoi(getenv("DNNCA_FZ_NT")) : 0;      // tuning aid

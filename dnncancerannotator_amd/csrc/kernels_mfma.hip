@@ -107,9 +107,24 @@ struct FwdArgs {
     int B, H, W;
     int tiles_x, tiles_y;
     float alpha;             // activation slope (<0: none)
+    // HEAD variant (the conv that feeds the annotator head, training): the head, the weighted BCE and the head's backward ride in
+    // this conv's epilogue (unet.py:241-244, losses.py:17-37) -- the feature map is not read again
+    const float* hy;         // labels [B, H, W]
+    const float* hw;         // head kernel (CO weights) and bias
+    const float* hb;
+    float* hdfeat;           // gradient of the feature map = gradient of this conv's output [B, H, W, CO]
+    float* hpartials;        // [gridDim.x][CO + 2] block partial sums (dW..., db, loss), reduced by k_pg_fold
+    double* hscalars;        // scalars[0] = label sum (k_label_stats ran earlier on the stream), or, with hlabel_part:
+    const float* hlabel_part;  // [hlabel_nblk][4] per-block (sum, min, max, -) of the labels from the first encoder block's launch
+    int hlabel_nblk;           //   -> every block sums them; block 0 also writes scalars[0..2] for the step outputs
+    dnnca_loss_cfg hcfg;
+    double hn_label;
+    float hgscale;
+    int hmask;               // multiply dfeat by act'(feat)
+    float halpha;
 };
 
-template <int C, int NSRC, int CO, int NT, bool DB>
+template <int C, int NSRC, int CO, int NT, bool DB, bool HEAD = false>
 __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
     constexpr int G = 12 / CO, TX = 2, TW = 16 * G * TX, N = G * CO, NW = NT / 64;
     using T = TG<C, TW>;
@@ -136,6 +151,56 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(breg[s]));
     asm volatile("" : "+v"(bias));
+
+    // HEAD: head weights, the positive-class weight (losses.py:24-29) and this lane's partial sums
+    float hwv[HEAD ? CO : 1], hbias = 0.f, hwgt = 1.f, hsum[HEAD ? CO + 2 : 1];
+    if constexpr (HEAD) {
+        static_assert(G * 16 == 64, "HEAD: one lane per pixel of an M-tile row (CO = 3)");
+#pragma unroll
+        for (int c = 0; c < CO; ++c) hwv[c] = p.hw[c];
+        hbias = p.hb[0];
+        double lsum;
+        if (p.hlabel_part) {
+            // label statistics of this step: per-block partials written by k_fz_down (no same-address atomics, no launch of their own)
+            double ds = 0.0;
+            float mn = INFINITY, mx = -INFINITY;
+            for (int i = tid; i < p.hlabel_nblk; i += NT) {
+                const float4 v = reinterpret_cast<const float4*>(p.hlabel_part)[i];
+                ds += (double)v.x;
+                mn = fminf(mn, v.y);
+                mx = fmaxf(mx, v.z);
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                ds += __shfl_down(ds, o, 64);
+                mn = fminf(mn, __shfl_down(mn, o, 64));
+                mx = fmaxf(mx, __shfl_down(mx, o, 64));
+            }
+            double* redd = reinterpret_cast<double*>(lds4);
+            float* redf = reinterpret_cast<float*>(lds4) + 2 * NW;
+            if (lane == 0) { redd[wave] = ds; redf[wave] = mn; redf[NW + wave] = mx; }
+            __syncthreads();
+            ds = 0.0; mn = INFINITY; mx = -INFINITY;
+            for (int w = 0; w < NW; ++w) { ds += redd[w]; mn = fminf(mn, redf[w]); mx = fmaxf(mx, redf[NW + w]); }
+            __syncthreads();                 // the LDS words are about to hold the first staged tile
+            lsum = ds;
+            if (blockIdx.x == 0 && tid == 0) { p.hscalars[0] = ds; p.hscalars[1] = (double)mn; p.hscalars[2] = (double)mx; }
+        } else {
+            lsum = p.hscalars[0];
+        }
+        if (p.hcfg.has_weight) {
+            hwgt = p.hcfg.weight;
+        } else {
+            const float pr = (float)(lsum / p.hn_label);
+            hwgt = pr > 0.f ? 1.0f / pr : 1.0f;
+        }
+        hwgt = p.hcfg.weight_mul * hwgt + p.hcfg.weight_add;
+#pragma unroll
+        for (int c = 0; c < CO + 2; ++c) hsum[c] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < CO; ++c) asm volatile("" : "+v"(hwv[c]));
+        asm volatile("" : "+v"(hbias), "+v"(hwgt));
+    }
 
     float4 pre[NSRC][T::npf(NT)];
     TileMap<C, TW, NT> mp;
@@ -174,6 +239,19 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
             lds_barrier();
         }
         const float* lds = reinterpret_cast<const float*>(lds4 + buf * STAGE4);
+        // HEAD: this tile's labels are loaded BEFORE the next tile's prefetch is issued: vmcnt retires in order, so a label load
+        // behind the prefetch would make the epilogue wait for the whole prefetch (an HBM round trip per tile)
+        float zlab[2] = {0.f, 0.f};
+        if constexpr (HEAD) {
+            const int tx_ = wave % TX, ty0_ = wave / TX;
+            const int px = x0 + tx_ * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int y = y0 + 2 * ty0_ + i;
+                const int pxc = px < p.W ? px : p.W - 1, yc = y < p.H ? y : p.H - 1;      // clamped: masked in the epilogue
+                zlab[i] = p.hy[((size_t)b * p.H + yc) * p.W + pxc];
+            }
+        }
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
@@ -223,6 +301,39 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
                     const float4 v = reinterpret_cast<const float4*>(orw)[lane];
                     *reinterpret_cast<float4*>(p.dst + ((size_t)b * p.H + y) * p.W * CO + f0) = v;
                 }
+                if constexpr (HEAD) {
+                    // one lane = one pixel of the 64-pixel row segment: logit -> weighted BCE -> dlogit -> dW, db, d(feature map)
+                    const int px = x0 + tx * 64 + lane;
+                    const bool ok = px < p.W && y < p.H;
+                    float f[CO], df[CO];
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) f[c] = orw[lane * CO + c];
+                    const float z = ok ? zlab[i] : 0.f;
+                    float xl = hbias;
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) xl = fmaf(f[c], hwv[c], xl);
+                    const float mk = fmaf(z, hwgt - 1.0f, 1.0f);
+                    const float e = expf(-fabsf(xl));
+                    const float sig = xl >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+                    const float dl = ok ? mk * (sig - z) * p.hgscale : 0.f;
+                    if (ok) hsum[CO + 1] = fmaf(fmaxf(xl, 0.f) - xl * z + log1pf(e), mk, hsum[CO + 1]);
+                    hsum[CO] += dl;
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) {
+                        hsum[c] = fmaf(f[c], dl, hsum[c]);
+                        float d = dl * hwv[c];
+                        if (p.hmask) d *= f[c] > 0.f ? 1.0f : p.halpha;
+                        df[c] = d;
+                    }
+                    __builtin_amdgcn_wave_barrier();        // every lane has read its features: the row can be overwritten
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) orw[lane * CO + c] = df[c];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 48 && f0 < p.W * CO && y < p.H) {
+                        const float4 v = reinterpret_cast<const float4*>(orw)[lane];
+                        *reinterpret_cast<float4*>(p.hdfeat + ((size_t)b * p.H + y) * p.W * CO + f0) = v;
+                    }
+                }
             }
             __builtin_amdgcn_wave_barrier();
             if (p.pool_dst) {
@@ -251,6 +362,22 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
         }
         lds_barrier();
         tile = next;
+    }
+    if constexpr (HEAD) {
+        // block partial sums: wave shuffles, the waves through LDS, one row of the partials table per block
+        float* red = reinterpret_cast<float*>(lds4);
+#pragma unroll
+        for (int k = 0; k < CO + 2; ++k) {
+            float v = hsum[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) red[wave * (CO + 2) + k] = v;
+        }
+        __syncthreads();
+        if (tid < CO + 2) {
+            float v = 0.f;
+            for (int w = 0; w < NW; ++w) v += red[w * (CO + 2) + tid];
+            p.hpartials[blockIdx.x * (CO + 2) + tid] = v;
+        }
     }
 }
 
@@ -1237,6 +1364,58 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     CONV_SHAPES(X)
 #undef X
     return false;
+}
+
+bool fast_head_in_conv_possible(Model* m) {
+    if (m->ops.size() < 2 || !m->head_defer_ok) return false;
+    const Op& head = m->ops.back();
+    const Op& o = m->ops[m->ops.size() - 2];
+    if (head.type != OP_HEAD || !conv_supported(m, o)) return false;
+    return o.inA.d.C == 3 && !o.inB.d.C && o.out.d.C == 3 && head.inA.d.p == o.out.d.p && head.inA.d.C == 3 && dense(head.inA.d);
+}
+
+// The conv that feeds the annotator head, in a training step: its forward launch also runs the head, the weighted BCE and the
+// head's backward (what k_head_train does in a launch of its own, re-reading the feature map).  The caller has made sure that
+// the label statistics of this step are already on the stream.  Returns false when the shape has no such kernel.
+bool fast_conv_fwd_head(Model* m, int B, Op& o, Op& head, const float* y, const dnnca_loss_cfg& cfg, float gscale, double bytes,
+                        double flops) {
+    if (!conv_supported(m, o) || !m->head_defer_ok) return false;
+    const int C = o.inA.d.C, NS = o.inB.d.C ? 2 : 1, CO = o.out.d.C;
+    if (C != 3 || NS != 1 || CO != 3 || head.inA.d.p != o.out.d.p || head.inA.d.C != 3 || !dense(head.inA.d)) return false;
+    PgPlan& pl = g_plans[m];
+    auto it = pl.slot.find({&o, 0});
+    if (it == pl.slot.end()) return false;
+    FwdArgs a{};
+    a.src[0] = o.inA.d.p; a.src[1] = nullptr;
+    a.bmat = pl.bmat + it->second;
+    a.bias = m->p + o.b_off;
+    a.dst = o.out.d.p;
+    a.pool_dst = nullptr;
+    a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
+    a.alpha = o.alpha;
+    a.hy = y;
+    a.hw = m->p + head.w_off; a.hb = m->p + head.b_off;
+    a.hdfeat = head.inA.g.p;
+    a.hpartials = m->head_partials;
+    a.hscalars = m->scalars;
+    a.hlabel_part = m->label_part_valid ? m->label_part : nullptr;
+    a.hlabel_nblk = m->label_part_nblk;
+    a.hcfg = cfg;
+    a.hn_label = (double)B * a.H * a.W;
+    a.hgscale = gscale;
+    a.hmask = head.maskA; a.halpha = head.mask_alpha;
+    const int TW = 32 * (12 / CO);
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    const int ntiles = a.tiles_x * a.tiles_y * B;
+    static const int fit = resident_blocks(k_pgfwd<3, 1, 3, 512, false, true>, 2048);      // partials table: 2048 rows
+    const int g = ntiles < fit ? ntiles : fit;
+    LAUNCH(m, "pgfwd_head_3x1_3", bytes, flops,
+           hipLaunchKernelGGL((k_pgfwd<3, 1, 3, 512, false, true>), dim3(g), dim3(512), 0, m->stream, a));
+    // the partial sums wait for the launch that ends the backward pass (k_pg_fold)
+    m->head_pending.partials = m->head_partials; m->head_pending.nblocks = g; m->head_pending.C = 3;
+    m->head_pending.dw = m->g + head.w_off; m->head_pending.dbias = m->g + head.b_off;
+    return true;
 }
 
 bool fast_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops) {

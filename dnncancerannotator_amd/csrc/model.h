@@ -96,6 +96,14 @@ struct Model {
     float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f;
     int last_batch = 0;
     bool defer_head = false, head_deferred = false;   // train step: the head runs fused with the loss and its backward
+    // train step on the pixel-group plan: the head rides in the epilogue of the conv that feeds it (fast_conv_fwd_head); forward()
+    // then needs the step's labels and loss configuration, and loss_and_backward() finds label statistics and head already done
+    // label statistics of a train step as per-block partials (sum, min, max, -) written by the first encoder block's fused launch
+    // (kernels_fused.hip) and consumed by the head-in-conv kernel: no launch and no atomics of their own
+    float* label_part = nullptr;
+    int label_part_nblk = 0;
+    bool label_part_valid = false;
+    struct HeadInConv { const float* y = nullptr; dnnca_loss_cfg cfg; bool requested = false, done = false, labels_done = false; } head_in_conv;
     // data parallel
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;

@@ -385,6 +385,24 @@ int Model::forward(const float* x_dev, int B, bool training) {
     step_init_done = false;
     DN_TRY(fast_prepare(this));
     DN_TRY(ig_prepare(this));
+    head_in_conv.done = false;
+    // the head will ride in the last conv's epilogue: it needs the label statistics (positive rate) of this step, so they go first
+    // (pg_prep has just zeroed the scalars)
+    bool head_in_conv_ok = head_in_conv.requested && !generic && (step_init_done || dry) && head_defer_ok && ops.size() >= 2 &&
+                           ops.back().type == OP_HEAD && fast_head_supported(this, ops.back());
+    // ... either from the first encoder block's fused launch (when the head-in-conv kernel will be there to consume its partials
+    // table; the label image is then the network's output geometry: the first block runs at full resolution) or from their own kernel
+    label_part_valid = false;
+    const float* labels_in_first_block = nullptr;
+    if (head_in_conv_ok) {
+        static const bool fuse_labels = getenv("DNNCA_NO_LABEL_FUSION") == nullptr;
+        if (fuse_labels && fast_head_in_conv_possible(this) && ops[0].type == OP_CONV && !ops[0].need_din && ops[0].out.d.H == outH &&
+            ops[0].out.d.W == outW)
+            labels_in_first_block = head_in_conv.y;
+        else
+            head_in_conv_ok = fast_label_stats(this, (size_t)B * outH * outW, head_in_conv.y);
+    }
+    head_in_conv.labels_done = head_in_conv_ok;
 
     const Op* pool_done = nullptr;      // a max-pool that rode in the preceding conv's epilogue
     for (size_t oi = 0; oi < ops.size(); ++oi) {
@@ -395,6 +413,25 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 int Cin = o.inA.d.C + o.inB.d.C;
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d) + nelem(B, o.out.d));
                 double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
+                if (head_in_conv_ok && oi + 2 == ops.size()) {                // the conv that feeds the head: head + loss + head backward in its epilogue
+                    const float gs = (float)(1.0 / ((double)outH * outW * B));
+                    const double npx = (double)B * outH * outW;
+                    if (fast_conv_fwd_head(this, B, o, ops.back(), head_in_conv.y, head_in_conv.cfg, gs, bytes + 4.0 * npx * (1 + o.out.d.C), flops + 30.0 * npx)) {
+                        head_in_conv.done = true;
+                        break;
+                    }
+                    if (label_part_valid) { set_error("internal: label partials without the head-in-conv kernel"); return DNNCA_ESTATE; }
+                }
+                if (oi == 0 && labels_in_first_block) {
+                    if (!generic && fused_down_fwd(this, B, oi, training, labels_in_first_block)) {
+                        oi += 2;
+                        break;
+                    }
+                    // the first block did not take them: the label statistics get their own launch after all
+                    head_in_conv_ok = fast_label_stats(this, (size_t)B * outH * outW, head_in_conv.y);
+                    head_in_conv.labels_done = head_in_conv_ok;
+                    labels_in_first_block = nullptr;
+                }
                 if (!generic && fused_down_fwd(this, B, oi, training)) {      // conv, conv, pool of one encoder block in one launch
                     oi += 2;
                     break;
@@ -476,7 +513,8 @@ int Model::forward(const float* x_dev, int B, bool training) {
 // ---------------------------------------------------------------------------------------------- loss + backward
 int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cfg, bool backward) {
     cur_op = nullptr;
-    head_pending.partials = nullptr;    // leftovers of a step that stopped on an error
+    if (!(backward && head_in_conv.done && y_dev == head_in_conv.y))
+        head_pending.partials = nullptr;    // leftovers of a step that stopped on an error (not: the head that just ran in the forward pass)
     fin_pending.on = false;
     if (cfg.label_smoothing) {          // utils/losses.py:62-67: every later use of y_true (positive rate, assertions, loss) sees the blurred labels
         if (!y_smooth) DN_TRY(alloc((void**)&y_smooth, (size_t)desc.max_batch * outH * outW * 4));
@@ -489,19 +527,26 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
     }
     const bool generic = desc.flags & 1;
     size_t npix = (size_t)B * outH * outW;
+    const bool labels_done = backward && head_in_conv.labels_done && y_dev == head_in_conv.y;
+    const bool head_was_in_conv = labels_done && head_in_conv.done;
+    head_in_conv.labels_done = head_in_conv.done = false;
     // scalars: label sum 0, min +inf, max -inf, loss 0, l2 0
     if (!(step_init_done && backward))
         LAUNCH(this, "g_step_init", 0, 0,
                g_step_init(stream, scalars, g, backward ? (size_t)(nT + 8) : 0, extra_zero,
                            backward && !generic ? extra_zero_n : 0));
     step_init_done = false;
-    if (generic || !fast_label_stats(this, npix, y_dev))
+    if (labels_done) {
+        // the forward pass of this train step already ran the label statistics (and maybe the head, in its last conv's epilogue)
+    } else if (generic || !fast_label_stats(this, npix, y_dev))
         LAUNCH(this, "g_label_stats", 4.0 * npix, (double)npix, g_label_stats(stream, npix, y_dev, scalars));
     // dlogits scale: mean over (H, W), then mean over the (rank-local) batch.  Under data parallel every rank uses its
     // local mean; the cross-rank 1/world is applied to the all-reduced gradient in the optimizer step.
     float gscale = (float)(1.0 / ((double)outH * outW * B));
     bool head_done = false;
-    if (backward && head_deferred) {
+    if (head_was_in_conv) {
+        head_done = true;
+    } else if (backward && head_deferred) {
         Op& ho = ops.back();
         double fb = 4.0 * nelem(B, ho.inA.d);
         if (!fast_head_train(this, B, ho, y_dev, cfg, gscale, 2 * fb + 4.0 * npix)) {
@@ -847,8 +892,13 @@ int dnnca_train_step_dev(void* model, const float* x_dev, const float* y_dev, in
     MODEL(model);
     if (!cfg) { set_error("null loss cfg"); return DNNCA_EINVAL; }
     M->defer_head = true;
+    // (label smoothing blurs the labels in loss_and_backward first: then the head cannot run inside the forward pass)
+    M->head_in_conv.requested = !cfg->label_smoothing && M->merged_launches() && !getenv("DNNCA_NO_HEAD_IN_CONV");
+    M->head_in_conv.y = y_dev;
+    M->head_in_conv.cfg = *cfg;
     int frc = M->forward(x_dev, batch, true);
     M->defer_head = false;
+    M->head_in_conv.requested = false;
     DN_TRY(frc);
     DN_TRY(M->loss_and_backward(y_dev, batch, *cfg, true));
     DN_TRY(M->optimizer_step(lr));
@@ -1151,8 +1201,12 @@ int dnnca_plan_dump(void* model, char* buf, size_t cap) {
     dnnca_loss_cfg cfg = {0, 0.f, 0.f, 1.f};
     int B = M->desc.max_batch;
     M->defer_head = true;
+    M->head_in_conv.requested = !getenv("DNNCA_NO_HEAD_IN_CONV");
+    M->head_in_conv.y = M->y_stage;
+    M->head_in_conv.cfg = cfg;
     int rc = M->forward(M->x_stage, B, true);
     M->defer_head = false;
+    M->head_in_conv.requested = false;
     if (rc == DNNCA_OK) rc = M->loss_and_backward(M->y_stage, B, cfg, true);
     if (rc == DNNCA_OK) rc = M->optimizer_step(1e-3f);
     M->dry = false;

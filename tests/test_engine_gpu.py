@@ -136,6 +136,34 @@ def test_full_size_tuned_vs_generic_and_directional_derivative(gpu):
     generic.close()
 
 
+def test_full_size_label_statistics_ride_in_the_first_block(gpu):
+    """At the BASELINE size the train step has no label-statistics launch and no head launch: the first encoder block's fused
+    kernel reduces the labels (utils/losses.py:87-102) into a partials table and the conv that feeds the head runs head + loss +
+    head backward in its epilogue.  The reference's assertions and the no-positives branch must still work through that path."""
+    from dnncancerannotator_amd.synthetic import synthetic_batch
+    B, H, W = 8, 512, 512
+    x, y = synthetic_batch(B, H, W, 1)
+    m = gpu.DeviceModel('unet', 1, H, W, B, **UNET)
+    m.init_glorot(seed=2)
+    names = [r[0] for r in m.plan()]
+    assert 'pgfwd_head_3x1_3' in names and 'fz_down_1_3' in names and 'label_stats4' not in names and 'head_train_3' not in names
+    cfg = m.loss_cfg(weight_mul=3.0, weight_add=0.25)
+    out = m.train_step(x, y, 0.0, cfg)
+    pr = float(y.astype(np.float64).mean())
+    assert abs(out.positive_rate - pr) <= 1e-6 * pr and out.label_min == 0.0 and out.label_max == 1.0
+    assert abs(out.weight - (3.0 / pr + 0.25)) <= 1e-4 * out.weight
+    out0 = m.train_step(x, np.zeros_like(y), 0.0, cfg)                      # no positives: weight = mul * 1 + add (losses.py:27)
+    assert out0.positive_rate == 0.0 and abs(out0.weight - 3.25) < 1e-6
+    bad = y.copy()
+    bad[5, 300, 17] = 1.5
+    with pytest.raises(Exception) as e:                                     # assert_on_max (utils/losses.py:91)
+        m.train_step(x, bad, 0.0, cfg)
+    assert 'label outside' in str(e.value)
+    ok = m.train_step(x, y, 0.0, cfg)                                       # and the model recovers
+    assert abs(ok.loss - out.loss) <= 1e-6 * abs(out.loss)
+    m.close()
+
+
 def test_full_size_batch_permutation_and_determinism(gpu):
     """BASELINE size (8 x 512 x 512 x 1), size-independent properties of the tuned path: the forward pass is bit-reproducible;
     permuting the slices of the batch permutes the logits exactly (no BatchNorm in configs/unet.yaml: slices are independent)
