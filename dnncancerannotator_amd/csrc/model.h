@@ -124,8 +124,9 @@ struct Model {
     int prof_mode = 0;                   // 0 off, 1 every launch, 2 only `focus`, 3 every launch keyed by kernel@layer
     const std::string* cur_op = nullptr;
     int prof_period = 1;                 // mode 2: bracket the focus kernel in one train step out of prof_period
-    // launches that ride in another kernel's launch keep doing so unless every launch is being timed by name (modes 1, 3)
-    bool merged_launches() const { return prof_mode == 0 || prof_mode == 2; }
+    // launches that ride in another kernel's launch keep doing so -- the profile table of mode 1 is the schedule that really runs
+    // (their work is then inside the carrying launch's row) -- except in the per-layer table of mode 3
+    bool merged_launches() const { return prof_mode != 3; }
     bool dry = false;
     std::string focus, plan_text;
     std::map<std::string, int> kid;

@@ -20,9 +20,9 @@ def short_name(k):
     m = re.match(r'dnnca::k_pgbwd<(\d+), (\d+), (\d+), (true|false)', k)
     if m:
         return 'pgbwd_%s%sx%s_%s' % ('' if m.group(4) == 'true' else 'w_', m.group(1), m.group(2), m.group(3))
-    m = re.match(r'dnnca::k_pgfwd<(\d+), (\d+), (\d+)', k)
+    m = re.match(r'dnnca::k_pgfwd<(\d+), (\d+), (\d+), \d+, (?:true|false)(, true)?>', k)
     if m:
-        return 'pgfwd_%sx%s_%s' % m.groups()
+        return 'pgfwd_%s%sx%s_%s' % ('head_' if m.group(4) else '', m.group(1), m.group(2), m.group(3))
     m = re.match(r'dnnca::k_(pool2_bwd|pool2_fwd|head_train|head_reduce)<(\d+)', k)
     if m:
         return '%s_%s' % m.groups()
