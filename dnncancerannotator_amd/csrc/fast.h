@@ -25,6 +25,7 @@ bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op*
 bool fast_first_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 bool fast_pool_fwd(Model* m, int B, Op& o, double bytes);
 bool fast_pool_bwd(Model* m, int B, Op& o, double bytes);
+bool fast_pool_fold(Model* m, Op& pool, Op& conv);      // the pool's backward rides in conv's backward launch (conv produced the pool's input)
 bool fast_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops);
 bool fast_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 bool fast_pool_supported(const Model* m, const Op& o);

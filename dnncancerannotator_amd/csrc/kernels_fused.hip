@@ -232,6 +232,8 @@ struct DownArgs {
     float* y0;               // conv1 output [B, H, W, C1] (nullptr: not stored -- inference)
     float* y1;               // conv2 output = skip [B, H, W, C1]
     float* pool;             // [B, H/2, W/2, C1]
+    unsigned char* pool_idx; // [B, H/2, W/2, C1] window position (0..3, row-major) of each pooled value's FIRST maximum, or nullptr:
+                             // the backward pass routes by it (k_pgbwd PF) instead of running a pool-backward launch
     int B, H, W, tiles_x, tiles_y;
     float alpha1, alpha2;
     // first block of a train step: the labels [B, H, W] of every tile are read alongside (tiles partition the image) and their
@@ -354,13 +356,19 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_down(DownArgs p) {
             for (int idx = tid; idx < (TH / 2) * PR4; idx += NT) {
                 const int r = idx / PR4, c4 = idx - r * PR4;
                 float o[4];
+                unsigned where = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int f = 4 * c4 + e, pp = f / C1, c = f - pp * C1;
                     const float* a = t2 + (2 * r) * T2::LS + T2::LEAD + (2 * pp) * C1 + c;
-                    o[e] = fmaxf(fmaxf(a[0], a[C1]), fmaxf(a[T2::LS], a[T2::LS + C1]));
+                    const float a0 = a[0], a1 = a[C1], a2 = a[T2::LS], a3 = a[T2::LS + C1];
+                    const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                    o[e] = mx;
+                    where |= (a0 == mx ? 0u : (a1 == mx ? 1u : (a2 == mx ? 2u : 3u))) << (8 * e);     // the order g_pool_bwd searches in
                 }
                 *reinterpret_cast<float4*>(pb + (size_t)r * Wp * C1 + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
+                if (p.pool_idx)
+                    *reinterpret_cast<unsigned*>(p.pool_idx + ((size_t)cb * Hp + (cy0 >> 1) + r) * Wp * C1 + (size_t)(cx0 >> 1) * C1 + 4 * c4) = where;
             }
         }
         if (!more) break;
@@ -613,6 +621,14 @@ bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* lab
     a.y0 = store_mid ? c1.out.d.p : nullptr;
     a.y1 = c2.out.d.p;
     a.pool = pl.out.d.p;
+    pl.pool_idx_valid = false;
+    if (store_mid && !m->dry) {       // a backward pass follows: record where every maximum sits
+        if (!pl.pool_idx) {
+            void* ix = nullptr;
+            if (m->alloc(&ix, (size_t)m->desc.max_batch * pl.out.d.H * pl.out.d.W * C1 + 16) == DNNCA_OK) pl.pool_idx = (unsigned char*)ix;
+        }
+        a.pool_idx = pl.pool_idx;
+    }
     a.B = B; a.H = H; a.W = W;
     a.alpha1 = c1.alpha; a.alpha2 = c2.alpha;
     if (labels) {         // the caller (forward of a train step) wants this step's label statistics from this launch
@@ -633,6 +649,7 @@ bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* lab
         LAUNCH(m, "fz_down_" #cin "_" #c1v, bytes, flops,                                                         \
                hipLaunchKernelGGL((fz::k_fz_down<cin, c1v, tw, th, nt, mw>), dim3(g), dim3(nt), 0, m->stream, a));   \
         if (labels) { m->label_part_valid = true; m->label_part_nblk = g; }                                       \
+        pl.pool_idx_valid = store_mid && (m->dry || a.pool_idx != nullptr);                                       \
         return true;                                                                                              \
     }
     static const int alt = getenv("DNNCA_FZ_NT") ? atoi(getenv("DNNCA_FZ_NT")) : 0;      // tuning aid

@@ -411,6 +411,13 @@ struct BwdArgs {
     int B, H, W;
     int tiles_x, tiles_y;
     float alpha;             // slope of the masked activation
+    // PF (pool fold): this conv's output feeds a 2x2 max-pool and a skip connection.  dz then holds only the skip gradient; the
+    // staging adds the pooled gradient at the window position the forward pass recorded and applies act'(y) -- what the
+    // pool-backward launch did in place (components.py:54; max-pool gradient goes to the first maximum)
+    const float* pf_y;               // this conv's output [B, H, W, CO]
+    const float* pf_dpool;           // gradient of the pooled tensor [B, H/2, W/2, CO]
+    const unsigned char* pf_idx;     // window position of every maximum [B, H/2, W/2, CO]
+    float pf_alpha;                  // slope of act'
     int dbg;                 // tuning aid (DNNCA_DBG): bit 0 skip the data-gradient phase, bit 1 skip the weight-gradient phase
     unsigned long long* stamps;   // tuning aid (DNNCA_STAMPS): [block][tile slot 0..3][8] s_memtime stamps of wave 0
 };
@@ -456,9 +463,10 @@ __device__ __forceinline__ int slab_index(int mrow, int n);
 // data-gradient MFMAs for the whole tile, waves [NW/2, NW) walk down pixel columns of the same staged tiles with a sliding
 // 3 x 3 x C window in registers and keep dW[dy][kx][ci][co] + db[co] in 84 accumulators per lane.  Every SIMD hosts one wave of
 // each kind (waves are dealt to SIMDs cyclically), so the two pipes run side by side.
-template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB, bool VW = false>
+template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB, bool VW = false, bool PF = false>
 __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs p) {
     constexpr int NW = NT / 64;
+    static_assert(!PF || (NSRC == 1 && C == CO && DGRAD && !VW && !DB), "PF: single-source C -> C conv with data gradient");
     static_assert(!VW || (C == 3 && CO == 3 && NT == 512 && DGRAD), "VW: 3 -> 3 channels, eight waves, with data gradient");
     constexpr int NWD = VW ? NW / 2 : NW;          // waves that run the data gradient
     using Wc = BW<C, NSRC, CO>;
@@ -470,8 +478,14 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     // DB: two stage buffers -> the next tile is committed while other waves still read the current one, one barrier per tile
     constexpr int STAGE4 = Wc::STAGE4, NBUF = DB ? 2 : 1;
     constexpr int MAIN4 = NBUF * STAGE4 > Wc::RED4 ? NBUF * STAGE4 : Wc::RED4;
-    __shared__ float4 lds4[MAIN4 + NW * 48 + 1];       // staged tiles (reused for the final reduction) + output rows + constants
+    // PF: pooled-gradient tile (floats) and window-position tile (bytes), TH/2 + 2 rows of TW/2 + 2 pixels, lead as for a halo-1 tile
+    constexpr int PFR = TH / 2 + 2, PFW = Wc::TW / 2 + 2, PFLEAD = (4 - CO % 4) % 4;
+    constexpr int PFLS = (PFLEAD + PFW * CO + 3) / 4 * 4, PFN4 = PF ? PFR * PFLS / 4 : 0, PFLI = PFLS / 4, PFNI = PF ? PFR * PFLI : 0;
+    __shared__ float4 lds4[MAIN4 + NW * 48 + 1 + PFN4 + (PFNI + 3) / 4];       // staged tiles (reused for the final reduction) + output rows + constants
     float* orow = reinterpret_cast<float*>(lds4 + MAIN4) + (threadIdx.x >> 6) * 192;
+    float* pf_dp = reinterpret_cast<float*>(lds4 + MAIN4 + NW * 48 + 1);
+    unsigned* pf_ix = reinterpret_cast<unsigned*>(lds4 + MAIN4 + NW * 48 + 1 + PFN4);
+    static_assert(PFN4 <= NT && PFNI <= NT, "one prefetch slot per thread for the pooled tiles");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4, n = m16;
@@ -529,6 +543,58 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     TileMap<C, TW, NT> mpx;
     mpg.init(tid, p.W * CO / 4);
     mpx.init(tid, p.W * C / 4);
+    float4 prey[PF ? TGg::npf(NT) : 1];      // PF: this conv's output, same tile geometry as dz
+    float4 predp = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned preix = 0;
+    auto pf_issue = [&](int b, int x0, int y0) {
+        if constexpr (PF) {
+            (void)tile_issue<CO, TW, NT>(prey, mpg, p.pf_y, b, x0, y0, p.B, p.H, p.W);
+            const int Hp = p.H >> 1, Wp = p.W >> 1, rowf = Wp * CO;
+            {
+                const int r = tid / PFLI, c4 = tid - r * PFLI;
+                const int gy = (y0 >> 1) - 1 + r, gf = ((x0 >> 1) - 1) * CO - PFLEAD + 4 * c4;
+                const bool ok = tid < PFN4 && (unsigned)gy < (unsigned)Hp && gf >= 0 && gf < rowf;
+                const size_t off = ok ? ((size_t)b * Hp + gy) * rowf + gf : 0;
+                predp = *reinterpret_cast<const float4*>(p.pf_dpool + off);
+                if (!ok) predp = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool oki = tid < PFNI && (unsigned)gy < (unsigned)Hp && gf >= 0 && gf < rowf;
+                preix = oki ? *reinterpret_cast<const unsigned*>(p.pf_idx + off) : 0xffffffffu;
+            }
+        }
+    };
+    // PF: commit the pooled tiles, then (after a barrier) turn the skip gradient in `preg` into dz:
+    //     dz = (dskip + (window position == recorded position ? dpool : 0)) * act'(y)
+    auto pf_commit_pooled = [&]() {
+        if constexpr (PF) {
+            if (tid < PFN4) reinterpret_cast<float4*>(pf_dp)[tid] = predp;
+            if (tid < PFNI) pf_ix[tid] = preix;
+        }
+    };
+    auto pf_transform = [&](unsigned ok) {
+        if constexpr (PF) {
+            const unsigned char* ixb = reinterpret_cast<const unsigned char*>(pf_ix);
+#pragma unroll
+            for (int k = 0; k < TGg::npf(NT); ++k) {
+                const int r = mpg.row[k], c4 = mpg.c4[k];
+                float g[4] = {preg[k].x, preg[k].y, preg[k].z, preg[k].w};
+                const float yv[4] = {prey[k].x, prey[k].y, prey[k].z, prey[k].w};
+                const bool in = (ok >> k) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int f = 4 * c4 + e - TGg::LEAD;               // float index from the left-halo pixel
+                    if (in && f >= 0 && f < (TW + 2) * CO) {
+                        const int px = f / CO, ch = f - px * CO;
+                        const int pr = ((r - 1) >> 1) + 1, pc = ((px - 1) >> 1) + 1;        // row / pixel in the pooled tiles
+                        const unsigned pos = (((unsigned)(r - 1) & 1u) << 1) | ((unsigned)(px - 1) & 1u);
+                        const int o = PFLEAD + pc * CO + ch;
+                        const float dp = ixb[pr * PFLS + o] == pos ? pf_dp[pr * PFLS + o] : 0.f;
+                        g[e] = (g[e] + dp) * (yv[e] > 0.f ? 1.0f : p.pf_alpha);
+                    }
+                }
+                preg[k] = make_float4(g[0], g[1], g[2], g[3]);
+            }
+        }
+    };
     unsigned okg = 0, okx = 0;
     auto decode = [&](int t, int& b, int& x0, int& y0) {
         // blocks b, b + 8, b + 16 ... share an XCD (and its L2): give each XCD one contiguous eighth of the tile sequence, so
@@ -544,6 +610,7 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         int b, x0, y0;
         decode(tile, b, x0, y0);
         okg = tile_issue<CO, TW, NT>(preg, mpg, p.dz, b, x0, y0, p.B, p.H, p.W);
+        pf_issue(b, x0, y0);
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], b, x0, y0, p.B, p.H, p.W);
     }
@@ -562,6 +629,11 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         decode(tile, b, x0, y0);
         STAMP(0);
         if (!DB) {
+            if constexpr (PF) {
+                pf_commit_pooled();
+                lds_barrier();
+                pf_transform(okg);
+            }
             tile_commit<CO, TW, NT>(preg, okg, lds4, tid);
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) tile_commit<C, TW, NT>(prex[s], okx, lds4 + TGg::N4 + s * TGx::N4, tid);
@@ -576,6 +648,7 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
             int nb, nx0, ny0;
             decode(next, nb, nx0, ny0);
             okg = tile_issue<CO, TW, NT>(preg, mpg, p.dz, nb, nx0, ny0, p.B, p.H, p.W);
+            pf_issue(nb, nx0, ny0);
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], nb, nx0, ny0, p.B, p.H, p.W);
         }
@@ -1326,6 +1399,27 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     const bool db = pl.double_buffer && ntiles >= 3 * nb;
     const double bytes = out_bytes + (o.need_din ? 2 : 1) * in_bytes;
     const double fl = (o.need_din ? 2 : 1) * flops;
+    // this conv's output feeds a max-pool whose backward has been folded into this launch (fast_pool_fold)
+    if (m->pool_fold.conv == &o) {
+        const Op& pool = *m->pool_fold.pool;
+        m->pool_fold.conv = nullptr;
+        a.pf_y = o.out.d.p;
+        a.pf_dpool = pool.out.g.p;
+        a.pf_idx = pool.pool_idx;
+        a.pf_alpha = pool.mask_alpha;
+        const double pb = 4.0 * (2 * (double)B * o.out.d.H * o.out.d.W * CO + 2 * (double)B * pool.out.d.H * pool.out.d.W * CO);
+#define PFX(c)                                                                                                          \
+        if (C == c) {                                                                                                   \
+            static const int fit = resident_blocks(k_pgbwd<c, 1, c, true, 512, false, false, true>, 1 << 20);           \
+            const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);                                       \
+            LAUNCH(m, "pgbwd_pool_" #c "x1_" #c, bytes + pb, fl,                                                        \
+                   hipLaunchKernelGGL((k_pgbwd<c, 1, c, true, 512, false, false, true>), dim3(g), dim3(512), 0, m->stream, a)); \
+            return true;                                                                                                \
+        }
+        PFX(3) PFX(6) PFX(12)
+#undef PFX
+        return false;
+    }
     // 3 -> 3 channels: the variant whose weight gradient runs on the vector ALU beside the data-gradient MFMAs
     // (measured, profiles/r02_vw_ab.txt: two sources 52.4 -> 48.2 us; one source 31.4 -> 32.0 us -- there the matrix pipe is not
     //  what the data-gradient waves wait for -- so the single-source conv keeps the all-MFMA kernel unless DNNCA_VW_ALL is set)
@@ -1364,6 +1458,25 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     CONV_SHAPES(X)
 #undef X
     return false;
+}
+
+// The backward of a 2x2 max-pool folded into the backward launch of the conv that produced its input: possible when the forward
+// pass recorded the window positions (the block-fused encoder kernel), the pool's input gradient already holds the skip gradient
+// (accumulate) and the pool applies act' of that conv (ReLU: ties at zero are killed by act'(0) = 0).  The caller then skips the
+// pool's own launch; the very next fast_conv_bwd call must be for `conv`.
+bool fast_pool_fold(Model* m, Op& pool, Op& conv) {
+    static const bool on = getenv("DNNCA_NO_POOL_FOLD") == nullptr;
+    if (!on || pool.type != OP_POOL || pool.k != 2 || !pool.pool_idx_valid || !(pool.pool_idx || m->dry)) return false;
+    if (!pool.accA || !pool.maskA || pool.mask_alpha != 0.f) return false;
+    if (!conv_supported(m, conv) || conv.inB.d.C || !conv.need_din || conv.out.d.p != pool.inA.d.p || !conv.premasked) return false;
+    const int C = conv.inA.d.C, CO = conv.out.d.C;
+    if (C != CO || !(C == 3 || C == 6 || C == 12)) return false;
+    const int TW = 32 * (12 / CO);
+    if (conv.out.d.W % TW || conv.out.d.H % TH || !dense(pool.out.g) || !dense(pool.out.d)) return false;
+    pool.pool_idx_valid = false;
+    m->pool_fold.conv = &conv;
+    m->pool_fold.pool = &pool;
+    return true;
 }
 
 bool fast_head_in_conv_possible(Model* m) {

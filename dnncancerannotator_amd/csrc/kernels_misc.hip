@@ -139,6 +139,7 @@ bool fast_pool_bwd(Model* m, int B, Op& o, double bytes) {
         return true;
     }
     if (!fast_pool_supported(m, o)) return false;
+    o.pool_idx_valid = false;          // (recorded window positions of this step, if any, are not used by this kernel)
     const int C = o.out.d.C, Ho = o.out.d.H, Wo = o.out.d.W;
     const int total = B * Ho * (Wo * C / 12);
     dim3 grid((total + 255) / 256);

@@ -638,6 +638,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 }
                 case OP_POOL: {
                     double bytes = 4.0 * (2 * nelem(B, o.inA.d) + 2 * nelem(B, o.out.d));
+                    if (!generic && i > 0 && fast_pool_fold(this, o, ops[i - 1])) break;      // rides in the next launch (the conv's backward)
                     if (!generic && fast_pool_bwd(this, B, o, bytes)) break;
                     if (!all_f32(o)) return DNNCA_ESTATE;
                     if (o.maskA) { set_error("internal: masked pool gradient has no tuned kernel"); return DNNCA_ESTATE; }

