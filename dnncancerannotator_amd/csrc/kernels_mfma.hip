@@ -485,7 +485,8 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     float* orow = reinterpret_cast<float*>(lds4 + MAIN4) + (threadIdx.x >> 6) * 192;
     float* pf_dp = reinterpret_cast<float*>(lds4 + MAIN4 + NW * 48 + 1);
     unsigned* pf_ix = reinterpret_cast<unsigned*>(lds4 + MAIN4 + NW * 48 + 1 + PFN4);
-    static_assert(PFN4 <= NT && PFNI <= NT, "one prefetch slot per thread for the pooled tiles");
+    constexpr int NPS = PF ? (PFN4 + NT - 1) / NT : 1;       // prefetch slots per thread for the pooled tiles (PFNI = PFN4)
+    static_assert(PFNI == PFN4, "the two pooled tiles have the same number of staging slots");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4, n = m16;
@@ -544,21 +545,23 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     mpg.init(tid, p.W * CO / 4);
     mpx.init(tid, p.W * C / 4);
     float4 prey[PF ? TGg::npf(NT) : 1];      // PF: this conv's output, same tile geometry as dz
-    float4 predp = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned preix = 0;
+    float4 predp[NPS];
+    unsigned preix[NPS];
     auto pf_issue = [&](int b, int x0, int y0) {
         if constexpr (PF) {
             (void)tile_issue<CO, TW, NT>(prey, mpg, p.pf_y, b, x0, y0, p.B, p.H, p.W);
             const int Hp = p.H >> 1, Wp = p.W >> 1, rowf = Wp * CO;
-            {
-                const int r = tid / PFLI, c4 = tid - r * PFLI;
+#pragma unroll
+            for (int k = 0; k < NPS; ++k) {
+                const int id = tid + k * NT;
+                const int r = id / PFLI, c4 = id - r * PFLI;
                 const int gy = (y0 >> 1) - 1 + r, gf = ((x0 >> 1) - 1) * CO - PFLEAD + 4 * c4;
-                const bool ok = tid < PFN4 && (unsigned)gy < (unsigned)Hp && gf >= 0 && gf < rowf;
+                const bool ok = id < PFN4 && (unsigned)gy < (unsigned)Hp && gf >= 0 && gf < rowf;
                 const size_t off = ok ? ((size_t)b * Hp + gy) * rowf + gf : 0;
-                predp = *reinterpret_cast<const float4*>(p.pf_dpool + off);
-                if (!ok) predp = make_float4(0.f, 0.f, 0.f, 0.f);
-                const bool oki = tid < PFNI && (unsigned)gy < (unsigned)Hp && gf >= 0 && gf < rowf;
-                preix = oki ? *reinterpret_cast<const unsigned*>(p.pf_idx + off) : 0xffffffffu;
+                predp[k] = *reinterpret_cast<const float4*>(p.pf_dpool + off);
+                if (!ok) predp[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                preix[k] = *reinterpret_cast<const unsigned*>(p.pf_idx + off);
+                if (!ok) preix[k] = 0xffffffffu;
             }
         }
     };
@@ -566,8 +569,14 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     //     dz = (dskip + (window position == recorded position ? dpool : 0)) * act'(y)
     auto pf_commit_pooled = [&]() {
         if constexpr (PF) {
-            if (tid < PFN4) reinterpret_cast<float4*>(pf_dp)[tid] = predp;
-            if (tid < PFNI) pf_ix[tid] = preix;
+#pragma unroll
+            for (int k = 0; k < NPS; ++k) {
+                const int id = tid + k * NT;
+                if (id < PFN4) {
+                    reinterpret_cast<float4*>(pf_dp)[id] = predp[k];
+                    pf_ix[id] = preix[k];
+                }
+            }
         }
     };
     auto pf_transform = [&](unsigned ok) {
@@ -1310,9 +1319,9 @@ int fast_prepare(Model* m) {
 // registers allow it, one for the heavy backward kernels -- launching 512 blocks of those ran them in two rounds and paid the
 // per-block prologue twice: 4-6 us on each of six kernels of the unet.yaml step).
 template <typename K>
-static int resident_blocks(K kernel, int cap) {
+static int resident_blocks(K kernel, int cap, int nt = 512) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nt, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     static const int maxocc = getenv("DNNCA_PG_MAXOCC") ? atoi(getenv("DNNCA_PG_MAXOCC")) : 3;      // tuning aid (2: -0.3 %, 4: same)
     if (per_cu > maxocc) per_cu = maxocc;
     const int n = 256 * per_cu;
