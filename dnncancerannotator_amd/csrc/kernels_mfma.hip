@@ -667,7 +667,7 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         if (DGRAD && !(DBG_FLAGS(p) & 1)) {
             // M-tiles of this wave: t = wave + 4j, j < MTX*TH/4; NCH of them are processed with interleaved MFMA chains
             constexpr int PERW = Wc::MTX * TH / NWD;
-            constexpr int NCH = PERW >= 4 ? 4 : PERW;
+            constexpr int NCH = (VW && NSRC == 1) ? 2 : (PERW >= 4 ? 4 : PERW);      // (VW, one source: two chains keep the kernel under 128 registers)
 #pragma unroll 1
             for (int j0 = 0; j0 < (VW && wave >= NWD ? 0 : PERW); j0 += NCH) {
 #pragma unroll
