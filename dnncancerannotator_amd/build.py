@@ -9,6 +9,9 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdnnca.so')
 SOURCES = ['model.hip', 'kernels_generic.hip', 'kernels_mfma.hip', 'kernels_fused.hip', 'kernels_misc.hip', 'kernels_igemm.hip', 'kernels_first.hip', 'kernels_aug.hip', 'debug_tools.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-unused-result']
+# per-file extras.  kernels_mfma.hip: no SLP vectorizer -- it packs the scalar FMA chains of k_bwd3v into v_pk_fma_f32 (no faster
+# than two v_fma_f32 on gfx950, and the even-aligned register pairs cost hundreds of v_mov and spills)
+EXTRA_FLAGS = {'kernels_mfma.hip': ['-fno-slp-vectorize']}
 
 
 def _newer(src_list, target):
@@ -30,7 +33,7 @@ def build_library(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _newer([s] + headers, o):
-            cmd = [hipcc] + FLAGS + (['-DDNNCA_TUNING'] if os.environ.get('DNNCA_TUNING') else []) + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (['-DDNNCA_TUNING'] if os.environ.get('DNNCA_TUNING') else []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -393,9 +393,14 @@ __device__ __forceinline__ unsigned long long stamp() {
     do {                                                                                                \
         if (p.stamps && wave == 0 && lane == 0 && it < 4) p.stamps[((size_t)blockIdx.x * 4 + it) * 8 + (i)] = stamp(); \
     } while (0)
+#define STAMP_END(i)                                                                                    \
+    do {                                                                                                \
+        if (p.stamps && wave == 0 && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + 3) * 8 + (i)] = stamp(); \
+    } while (0)
 #define DBG_FLAGS(p) ((p).dbg)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP_END(i) do { } while (0)
 #define DBG_FLAGS(p) 0
 #endif
 
@@ -980,6 +985,238 @@ __global__ __launch_bounds__(256) void k_pg_prep(const int* __restrict__ index, 
     bmat[i] = j >= 0 ? params[j] : 0.f;
 }
 
+// ================================================================================================ backward, 3 -> 3 channels, vector ALU
+// k_bwd3v: the whole backward of a single-source 3 -> 3 channel conv (the 512^2 level) without the matrix cores.
+// With 3 channels the pixel-group GEMM fills a third of each MFMA (structural zeros): 31 thirty-two-cycle MFMAs per 64 pixels for
+// data + weight gradient = 992 matrix-pipe cycles per SIMD, 72 % of k_pgbwd<3,1,3>'s time.  As plain FMAs the same work is 162 per
+// pixel = 324 vector-ALU cycles per 64 pixels (v_fma_f32: 2 cycles per wave on a SIMD-32), with no waste.
+// Both gradients read the SAME 3 x 3 x 3 window of dz around a pixel q:
+//     dx[q][ci]            = sum_{wy,wx,co} win[wy][wx][co] * W[2-wy][2-wx][ci][co]        (81 FMAs, the weight is an SGPR operand)
+//     dW[2-wy][2-wx][ci][co] += x[q][ci] * win[wy][wx][co]                                  (81 FMAs, 81 accumulators per lane)
+//     db[co]               += win[1][1][co]
+// so one lane per pixel does everything from 27 window registers: a wave owns 64 columns x 4 rows of a 128 x 8 tile and walks down
+// its rows with a rotating three-row window (9 LDS reads per pixel).  Only dz is staged through LDS (register-prefetched halo tile,
+// as in k_pgbwd); x is needed at q alone (outer product, act' mask), so every lane loads its own 12 bytes straight from global,
+// software-pipelined one tile ahead row by row.  256-thread blocks, three per CU (<= 168 registers).
+// Same slab / fold protocol and the same pool-fold transform (PF) as k_pgbwd.
+template <bool PF, int ABL = 0>      // ABL (tuning builds): 1 = no FMAs (traffic, staging and barriers only)
+__global__ __launch_bounds__(256, 2) void k_bwd3v(BwdArgs p, const float* __restrict__ wts) {
+    constexpr int C = 3, CO = 3, NT = 256, TW = 128, R = 4;
+    static_assert(TH == 2 * R, "two wave rows of R output rows");
+    using TGg = TG<CO, TW>;
+    constexpr int LS = TGg::LS, LS4 = TGg::LS4, N4 = TGg::N4, NPF = TGg::npf(NT), WRw = 18, MT = 4;   // WRw / MT: slab geometry of k_pgbwd<3,1,3>
+    constexpr int PFR = TH / 2 + 2, PFW = TW / 2 + 2, PFLEAD = 1, PFLS = (PFLEAD + PFW * CO + 3) / 4 * 4, PFN4 = PF ? PFR * PFLS / 4 : 0;
+    __shared__ float4 lds4[N4 + PFN4 + (PFN4 + 3) / 4 + 84];
+    const float* gl = reinterpret_cast<const float*>(lds4);     // dz tile
+    float* pf_dp = reinterpret_cast<float*>(lds4 + N4);
+    unsigned* pf_ix = reinterpret_cast<unsigned*>(lds4 + N4 + PFN4);
+    float* red = reinterpret_cast<float*>(lds4 + N4 + PFN4 + (PFN4 + 3) / 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;              // the host guarantees W % TW == 0 and H % TH == 0: whole tiles only
+    const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+    const int rowlen4 = p.W * CO / 4;
+    const float slope = p.mask[0] ? p.alpha : 1.0f;             // act'(x) for x <= 0 (1: no mask)
+
+    // the 81 weights as wave-uniform values (scalar registers): w[((dy*3 + kx)*3 + ci)*3 + co], HWIO
+    float w[81];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wts[i])));
+
+    const int col = (wave & 1) * 64 + lane, rbase = (wave >> 1) * R;     // this lane's pixel column and first output row in the tile
+
+    float4 preg[NPF], prey[PF ? NPF : 1];
+    unsigned okg = 0;
+    constexpr int NPS = PF ? (PFN4 + NT - 1) / NT : 1;
+    float4 predp[NPS];
+    unsigned preix[NPS];
+    float xq[R][3];               // x of this lane's R pixels: loaded one tile ahead, row by row
+    // tile t -> (grow0, x0, y0): grow0 = b*H + y0 is the tile's first row counted through the whole batch
+    auto decode = [&](int t, int& grow0, int& x0, int& y0) {
+        t = xcd_map ? (t & 7) * (ntiles >> 3) + (t >> 3) : t;
+        const int trow = t / p.tiles_x;
+        x0 = (t - trow * p.tiles_x) * TW;
+        grow0 = trow * TH;
+        y0 = (trow % p.tiles_y) * TH;
+    };
+    // staging slot k of this thread: (tile row, 16-byte column) -- recomputed, not kept (registers)
+    auto slot = [&](int k, int& row, int& c4) {
+        const int idx = tid + k * NT;
+        row = idx / LS4;
+        c4 = idx - row * LS4;
+    };
+    auto issue_tile = [&](float4* pre, const float* __restrict__ src, int grow0, int x0, int y0) {
+        const float4* base = reinterpret_cast<const float4*>(src);
+        const int g40 = (x0 * CO - TGg::HL) / 4;
+        unsigned ok = 0;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            int row, c4;
+            slot(k, row, c4);
+            const int iy = y0 - 1 + row, g4 = g40 + c4;
+            const bool in = tid + k * NT < N4 && (unsigned)iy < (unsigned)p.H && (unsigned)g4 < (unsigned)rowlen4;
+            ok |= in ? (1u << k) : 0u;
+            pre[k] = base[in ? (grow0 - 1 + row) * rowlen4 + g4 : 0];
+        }
+        return ok;
+    };
+    auto issue = [&](int grow0, int x0, int y0) {
+        okg = issue_tile(preg, p.dz, grow0, x0, y0);
+        if constexpr (PF) {
+            (void)issue_tile(prey, p.pf_y, grow0, x0, y0);
+            const int Hp = p.H >> 1, rowf = (p.W >> 1) * CO;
+#pragma unroll
+            for (int k = 0; k < NPS; ++k) {
+                const int id = tid + k * NT;
+                const int r = id / (PFLS / 4), c4 = id - r * (PFLS / 4);
+                const int gy = (y0 >> 1) - 1 + r, gf = ((x0 >> 1) - 1) * CO - PFLEAD + 4 * c4;
+                const bool ok = id < PFN4 && (unsigned)gy < (unsigned)Hp && gf >= 0 && gf < rowf;
+                const size_t off = ok ? ((size_t)((grow0 >> 1) - 1 + r)) * rowf + gf : 0;
+                predp[k] = *reinterpret_cast<const float4*>(p.pf_dpool + off);
+                if (!ok) predp[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                preix[k] = *reinterpret_cast<const unsigned*>(p.pf_idx + off);
+                if (!ok) preix[k] = 0xffffffffu;
+            }
+        }
+    };
+    auto issue_x = [&](int rr, int grow0, int x0) {
+        const float* xp = p.x[0] + ((size_t)(grow0 + rbase + rr) * p.W + x0 + col) * C;
+        xq[rr][0] = xp[0]; xq[rr][1] = xp[1]; xq[rr][2] = xp[2];
+    };
+    auto commit = [&]() {
+        if constexpr (PF) {
+#pragma unroll
+            for (int k = 0; k < NPS; ++k) {
+                const int id = tid + k * NT;
+                if (id < PFN4) {
+                    reinterpret_cast<float4*>(pf_dp)[id] = predp[k];
+                    pf_ix[id] = preix[k];
+                }
+            }
+            lds_barrier();
+            const unsigned char* ixb = reinterpret_cast<const unsigned char*>(pf_ix);
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                int r, c4;
+                slot(k, r, c4);
+                float g[4] = {preg[k].x, preg[k].y, preg[k].z, preg[k].w};
+                const float yv[4] = {prey[k].x, prey[k].y, prey[k].z, prey[k].w};
+                const bool in = (okg >> k) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int f = 4 * c4 + e - TGg::LEAD;
+                    if (in && f >= 0 && f < (TW + 2) * CO) {
+                        const int px = f / CO, ch = f - px * CO;
+                        const int pr = ((r - 1) >> 1) + 1, pc = ((px - 1) >> 1) + 1;
+                        const unsigned pos = (((unsigned)(r - 1) & 1u) << 1) | ((unsigned)(px - 1) & 1u);
+                        const int o = PFLEAD + pc * CO + ch;
+                        const float dp = ixb[pr * PFLS + o] == pos ? pf_dp[pr * PFLS + o] : 0.f;
+                        g[e] = (g[e] + dp) * (yv[e] > 0.f ? 1.0f : p.pf_alpha);
+                    }
+                }
+                preg[k] = make_float4(g[0], g[1], g[2], g[3]);
+            }
+        }
+        tile_commit<CO, TW, NT>(preg, okg, lds4, tid);
+    };
+
+    float acc[84];                // acc[((wy*3 + wx)*3 + ci)*3 + co] = dW[2-wy][2-wx][ci][co] of this lane's pixels; acc[81 + co] = db[co]
+#pragma unroll
+    for (int i = 0; i < 84; ++i) acc[i] = 0.f;
+
+    int tile = blockIdx.x, it = 0;
+    (void)it;          // read by the tuning build's stamps only
+    STAMP(6);
+    if (tile < ntiles) {
+        int grow0, x0, y0;
+        decode(tile, grow0, x0, y0);
+        issue(grow0, x0, y0);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) issue_x(rr, grow0, x0);
+    }
+#pragma unroll 1
+    while (tile < ntiles) {
+        int grow0, x0, y0;
+        decode(tile, grow0, x0, y0);
+        STAMP(0);
+        commit();
+        lds_barrier();
+        STAMP(1);
+        // The prefetch is issued unconditionally (past the end: the last tile again, never committed): with every vector-memory
+        // operation of the loop in straight-line code hipcc counts its s_waitcnt vmcnt(N) exactly; a conditional load made it wait
+        // for the prefetch it had just issued (vmcnt retires in order), a full HBM round trip per tile.
+        const int next = tile + gridDim.x;
+        int ngrow0, nx0, ny0;
+        decode(min(next, ntiles - 1), ngrow0, nx0, ny0);
+        issue(ngrow0, nx0, ny0);
+        STAMP(2);
+        const float* gb = gl + rbase * LS + TGg::LEAD + col * CO;     // tile row rbase = output row rbase - 1; pixels col-1 .. col+1
+        float* dst = p.dx[0] + ((size_t)(grow0 + rbase) * p.W + x0 + col) * C;
+        float win[3][9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { win[0][i] = gb[i]; win[1][i] = gb[LS + i]; }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) win[(rr + 2) % 3][i] = gb[(rr + 2) * LS + i];
+            const float xv[3] = {xq[rr][0], xq[rr][1], xq[rr][2]};
+            float dx[3] = {0.f, 0.f, 0.f};
+            if constexpr (ABL & 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) dx[i % 3] += win[(rr + 2) % 3][i] + xv[i % 3];
+            } else
+#pragma unroll
+            for (int wy = 0; wy < 3; ++wy)
+#pragma unroll
+                for (int wx = 0; wx < 3; ++wx)
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        const float d = win[(rr + wy) % 3][wx * 3 + co];
+#pragma unroll
+                        for (int ci = 0; ci < 3; ++ci) {
+                            dx[ci] = fmaf(d, w[(((2 - wy) * 3 + (2 - wx)) * 3 + ci) * 3 + co], dx[ci]);
+                            acc[((wy * 3 + wx) * 3 + ci) * 3 + co] = fmaf(xv[ci], d, acc[((wy * 3 + wx) * 3 + ci) * 3 + co]);
+                        }
+                    }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) acc[81 + co] += win[(rr + 1) % 3][3 + co];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) dx[ci] *= xv[ci] > 0.f ? 1.0f : slope;
+            float* d3 = dst + (size_t)rr * p.W * C;
+            d3[0] = dx[0]; d3[1] = dx[1]; d3[2] = dx[2];
+            issue_x(rr, ngrow0, nx0);                              // this row's registers are free: the next tile's x row
+        }
+        STAMP(3);
+        lds_barrier();
+        STAMP(4);
+        ++it;
+        tile = next;
+    }
+    STAMP_END(5);
+    // lane sums by DPP, the four waves through LDS, one atomic per element into slab (blockIdx % NBUCKET), laid out where
+    // k_pg_fold expects D[(dy, j), (dx, co)]: everything in the dx = 0 entries (j = kx*3 + ci), the bias in the all-ones row
+#pragma unroll
+    for (int i = 0; i < 84; ++i) {
+        const float t = wave_total_l63(acc[i]);
+        if (lane == 63) red[wave * 84 + i] = t;
+    }
+    __syncthreads();
+    if (tid < 84) {
+        const int e = tid;
+        const float v = (red[e] + red[84 + e]) + (red[168 + e] + red[252 + e]);
+        int mrow, co;
+        if (e < 81) {
+            const int tap = e / 9, ci = (e / 3) % 3;
+            co = e % 3;
+            mrow = (2 - tap / 3) * WRw + (2 - tap % 3) * 3 + ci;
+        } else {
+            mrow = 3 * WRw;
+            co = e - 81;
+        }
+        atomicAdd(p.slabs[0] + (size_t)(blockIdx.x % NBUCKET) * (MT * 256) + slab_index(mrow, co), v);
+    }
+    STAMP_END(7);
+}
+
 // ================================================================================================ fold
 struct FoldDesc {
     int slab_off, nslabs, MT;      // slabs of this (op, source): floats offset into the slab buffer
@@ -1408,6 +1645,40 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     const bool db = pl.double_buffer && ntiles >= 3 * nb;
     const double bytes = out_bytes + (o.need_din ? 2 : 1) * in_bytes;
     const double fl = (o.need_din ? 2 : 1) * flops;
+    // single-source 3 -> 3 channels: the all-vector-ALU backward (k_bwd3v), with or without the pool fold
+    static const bool v3_on = getenv("DNNCA_NO_BWD3V") == nullptr;
+    if (v3_on && o.need_din && C == 3 && CO == 3 && NS == 1 && !o.accA && a.W % 128 == 0 && a.H % TH == 0) {
+        const bool pf = m->pool_fold.conv == &o;
+        double pb = 0.0;
+        if (pf) {
+            const Op& pool = *m->pool_fold.pool;
+            m->pool_fold.conv = nullptr;
+            a.pf_y = o.out.d.p;
+            a.pf_dpool = pool.out.g.p;
+            a.pf_idx = pool.pool_idx;
+            a.pf_alpha = pool.mask_alpha;
+            pb = 4.0 * (2 * (double)B * o.out.d.H * o.out.d.W * CO + 2 * (double)B * pool.out.d.H * pool.out.d.W * CO);
+        }
+        const float* wts = m->p + o.w_off;
+        if (a.stamps && pf != (getenv("DNNCA_STAMPS_PF") != nullptr)) a.stamps = nullptr;       // tuning aid: which of the two launches is stamped
+        if (pf) {
+            static const int fit = resident_blocks(k_bwd3v<true>, 1 << 20, 256);
+            const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);
+            LAUNCH(m, "bwd3v_pool_3x1_3", bytes + pb, fl, hipLaunchKernelGGL(k_bwd3v<true>, dim3(g), dim3(256), 0, m->stream, a, wts));
+        } else {
+            static const int fit = resident_blocks(k_bwd3v<false>, 1 << 20, 256);
+            const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);
+#ifdef DNNCA_TUNING
+            static const int abl = getenv("DNNCA_ABL") ? atoi(getenv("DNNCA_ABL")) : 0;
+            if (abl == 1) {
+                LAUNCH(m, "bwd3v_3x1_3", bytes, fl, hipLaunchKernelGGL((k_bwd3v<false, 1>), dim3(g), dim3(256), 0, m->stream, a, wts));
+                return true;
+            }
+#endif
+            LAUNCH(m, "bwd3v_3x1_3", bytes, fl, hipLaunchKernelGGL(k_bwd3v<false>, dim3(g), dim3(256), 0, m->stream, a, wts));
+        }
+        return true;
+    }
     // this conv's output feeds a max-pool whose backward has been folded into this launch (fast_pool_fold)
     if (m->pool_fold.conv == &o) {
         const Op& pool = *m->pool_fold.pool;

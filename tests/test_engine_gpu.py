@@ -440,6 +440,34 @@ def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
     m.close()
 
 
+@pytest.mark.parametrize('B, H, W', [(2, 40, 128), (8, 16, 256)])
+def test_vector_alu_backward_of_the_3_channel_level_against_oracle(gpu, B, H, W):
+    """configs/unet.yaml on images whose first level is made of whole 128 x 8 tiles: the single-source 3 -> 3 channel convs of
+    that level then run the all-vector-ALU backward kernel (k_bwd3v: data + weight + bias gradient from one register window,
+    with and without the folded max-pool backward) -- against the float64 oracle, every variable on its own scale.  The second
+    shape has a tile count divisible by 8 (the XCD-aware tile order)."""
+    spec = O.ModelSpec('unet', 1, **UNET)
+    params = Hp.perturbed_params(spec, np.float64)
+    rng = np.random.default_rng(13)
+    x = rng.random((B, H, W, 1)).astype(np.float32)
+    y = (rng.random((B, H, W)) < 0.05).astype(np.float32)
+    cfg = dict(weight_mul=3.0)
+    loss, grads, logits, _ = O.loss_and_grads(spec, params, x.astype(np.float64), y, cfg, training=True)
+    m = gpu.DeviceModel('unet', 1, H, W, B, **UNET)
+    m.set_params(O.flatten(spec, params))
+    out = m.train_step(x, y, 0.0, m.loss_cfg(**cfg))
+    assert abs(out.loss - loss) <= 1e-4 * max(1.0, abs(loss))
+    p32 = {n: v.astype(np.float32) for n, v in params.items()}
+    _, g32, _, _ = O.loss_and_grads(spec, p32, x, y, cfg, training=True)
+    gref, g32 = O.flatten(spec, grads), O.flatten(spec, g32).astype(np.float64)
+    floor = [10 * np.abs(g32[sl] - gref[sl]).max() for _, sl in Hp.tensor_slices(spec)]
+    Hp.assert_grads_per_tensor(spec, m.get_grads(), gref, 2e-5, floor=floor)
+    plan = set(r[0] for r in m.plan())
+    assert 'bwd3v_3x1_3' in plan, plan
+    assert 'bwd3v_pool_3x1_3' in plan or not any(k.startswith('fz_down') for k in plan), plan
+    m.close()
+
+
 def test_rccl_one_rank_rehearsal(gpu):
     """The RCCL calls of the DP path (unique id, communicator, gradient all-reduce on the step's stream, broadcast,
     state average, host all-reduce) on a one-rank communicator: a sum over one rank is the identity, so weights, BN
