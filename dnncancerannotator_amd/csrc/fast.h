@@ -17,6 +17,8 @@ bool fast_conv_fwd_head(Model* m, int B, Op& o, Op& head, const float* y, const 
 // kernels_fused.hip: a whole Downsample / Upsample block (components.py:77-81, 158-166) of configs/unet.yaml in one launch;
 // ops[oi .. oi+2] are consumed when these return true.  store_mid: also write the block's intermediate tensors (a backward pass follows)
 bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* labels = nullptr);   // labels: also reduce them (first block only)
+// ... or, where the shape allows, that conv's forward, the head, the loss and the conv's whole backward in one launch (sets Model::tail_done)
+bool fast_tail3(Model* m, int B, Op& o, Op& head, const float* y, const dnnca_loss_cfg& cfg, float gscale);
 bool fast_head_in_conv_possible(Model* m);      // would fast_conv_fwd_head take the conv that feeds the head?
 bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);

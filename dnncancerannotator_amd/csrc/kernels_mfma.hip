@@ -985,6 +985,10 @@ __global__ __launch_bounds__(256) void k_pg_prep(const int* __restrict__ index, 
     bmat[i] = j >= 0 ? params[j] : 0.f;
 }
 
+}  // namespace dnnca
+#include "strip_dev.h"
+namespace dnnca {
+
 // ================================================================================================ backward, 3 -> 3 channels, vector ALU
 // k_bwd3v: the whole backward of a single-source 3 -> 3 channel conv (the 512^2 level) without the matrix cores.
 // With 3 channels the pixel-group GEMM fills a third of each MFMA (structural zeros): 31 thirty-two-cycle MFMAs per 64 pixels for
@@ -1808,6 +1812,74 @@ bool fast_conv_fwd_head(Model* m, int B, Op& o, Op& head, const float* y, const 
     // the partial sums wait for the launch that ends the backward pass (k_pg_fold)
     m->head_pending.partials = m->head_partials; m->head_pending.nblocks = g; m->head_pending.C = 3;
     m->head_pending.dw = m->g + head.w_off; m->head_pending.dbias = m->g + head.b_off;
+    return true;
+}
+
+// The conv that feeds the head in a training step, whole: forward + head + weighted BCE + head backward + the conv's own backward
+// in one column-strip launch (k_tail3, strip_dev.h).  The conv's output and its gradient are never written; the caller skips the
+// conv's backward launch (Model::tail_done).  Returns false when the shape has no such kernel.
+bool fast_tail3(Model* m, int B, Op& o, Op& head, const float* y, const dnnca_loss_cfg& cfg, float gscale) {
+    if (getenv("DNNCA_NO_TAIL3") || !conv_supported(m, o) || !m->head_defer_ok) return false;      // (read per call: the tests flip it)
+    const int C = o.inA.d.C, NS = o.inB.d.C ? 2 : 1, CO = o.out.d.C;
+    if (C != 3 || NS != 1 || CO != 3 || head.inA.d.p != o.out.d.p || head.inA.d.C != 3 || !dense(head.inA.d)) return false;
+    if (!o.need_din || o.accA || !dense(o.inA.d) || !dense(o.inA.g) || (o.alpha >= 0.f && !o.premasked)) return false;
+    const int H = o.out.d.H, W = o.out.d.W;
+    if ((double)B * H * W * 12.0 >= 1073741824.0 || W < 8 || H < 8 || o.alpha > 1.f) return false;      // byte offsets below STRIP_HALF
+    PgPlan& pl = g_plans[m];
+    auto it = pl.wslot.find({&o, 0});
+    if (it == pl.wslot.end()) return false;
+    TailArgs a{};
+    a.x = o.inA.d.p;
+    a.w = m->p + o.w_off; a.bias = m->p + o.b_off;
+    a.alpha = o.alpha;
+    a.hy = y;
+    a.hw = m->p + head.w_off; a.hb = m->p + head.b_off;
+    a.hpartials = m->head_partials;
+    a.hscalars = m->scalars;
+    a.hlabel_part = m->label_part_valid ? m->label_part : nullptr;
+    a.hlabel_nblk = m->label_part_nblk;
+    a.hcfg = cfg;
+    a.hn_label = (double)B * H * W;
+    a.hgscale = gscale;
+    a.hmask = head.maskA; a.halpha = head.mask_alpha;
+    a.dx = o.inA.g.p;
+    a.mask = o.maskA; a.mask_alpha = o.mask_alpha;
+    a.slabs = pl.slabs + pl.folds[it->second].slab_off;
+    a.B = B; a.H = H; a.W = W;
+    a.nstrips = (W + STRIP - 1) / STRIP;
+    // one round of waves: 2 per SIMD on 256 CUs = 2048 tasks at most, in chunks of at least 8 rows
+    static const int slots = getenv("DNNCA_TAIL3_SLOTS") ? atoi(getenv("DNNCA_TAIL3_SLOTS")) : 2048;      // tuning aid
+    int nchunks = slots / (B * a.nstrips);
+    if (nchunks > H / 8) nchunks = H / 8;
+    if (nchunks < 1) nchunks = 1;
+    a.nchunks = nchunks;
+    const int ntasks = B * nchunks * a.nstrips, nblk = (ntasks + 3) / 4;
+    if (nblk > 2048) return false;                      // rows of the head's partials table
+    const double npx = (double)B * H * W;
+    static const int variant = getenv("DNNCA_TAIL3_VARIANT") ? atoi(getenv("DNNCA_TAIL3_VARIANT")) : 0;      // tuning aid
+    static const int tail3_lds = getenv("DNNCA_TAIL3_LDS") ? atoi(getenv("DNNCA_TAIL3_LDS")) : 0;      // tuning aid: dynamic LDS bytes (limits blocks per CU)
+    auto kern = k_tail3<3, 27, true, 0, 1>;
+#ifdef DNNCA_TUNING
+    if (variant == 1) kern = k_tail3<3, 27, true>;
+    if (variant == 2) kern = k_tail3<6, 27, true>;
+    if (variant == 3) kern = k_tail3<3, 0, true>;
+    if (variant == 4) kern = k_tail3<3, 54, true>;
+    if (variant == 5) kern = k_tail3<3, 45, true>;
+    if (variant == 6) kern = k_tail3<3, 27, true, 0, 1>;
+    if (variant == 7) kern = k_tail3<3, 27, false, 0, 1>;
+    if (variant == 8) kern = k_tail3<6, 27, false, 0, 1>;
+    if (variant == 9) kern = k_tail3<6, 27, true, 0, 1>;
+    if (variant >= 100) {
+        const int abl = variant - 100;
+        kern = abl == 1 ? k_tail3<3, 27, true, 1> : abl == 2 ? k_tail3<3, 27, true, 2> : abl == 4 ? k_tail3<3, 27, true, 4> : abl == 8 ? k_tail3<3, 27, true, 8>
+             : abl == 16 ? k_tail3<3, 27, true, 16> : abl == 7 ? k_tail3<3, 27, true, 7> : k_tail3<3, 27, true, 31>;
+    }
+#endif
+    LAUNCH(m, "tail3_3x1_3", 4.0 * npx * (3 + 1 + 3), 2.0 * npx * (81 * 3 + 4),
+           hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), tail3_lds, m->stream, a));
+    m->head_pending.partials = m->head_partials; m->head_pending.nblocks = nblk; m->head_pending.C = 3;
+    m->head_pending.dw = m->g + head.w_off; m->head_pending.dbias = m->g + head.b_off;
+    m->tail_done = &o;
     return true;
 }
 

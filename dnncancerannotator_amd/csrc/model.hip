@@ -386,6 +386,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
     DN_TRY(fast_prepare(this));
     DN_TRY(ig_prepare(this));
     head_in_conv.done = false;
+    tail_done = nullptr;
     // the head will ride in the last conv's epilogue: it needs the label statistics (positive rate) of this step, so they go first
     // (pg_prep has just zeroed the scalars)
     bool head_in_conv_ok = head_in_conv.requested && !generic && (step_init_done || dry) && head_defer_ok && ops.size() >= 2 &&
@@ -416,7 +417,8 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 if (head_in_conv_ok && oi + 2 == ops.size()) {                // the conv that feeds the head: head + loss + head backward in its epilogue
                     const float gs = (float)(1.0 / ((double)outH * outW * B));
                     const double npx = (double)B * outH * outW;
-                    if (fast_conv_fwd_head(this, B, o, ops.back(), head_in_conv.y, head_in_conv.cfg, gs, bytes + 4.0 * npx * (1 + o.out.d.C), flops + 30.0 * npx)) {
+                    if (fast_tail3(this, B, o, ops.back(), head_in_conv.y, head_in_conv.cfg, gs) ||
+                        fast_conv_fwd_head(this, B, o, ops.back(), head_in_conv.y, head_in_conv.cfg, gs, bytes + 4.0 * npx * (1 + o.out.d.C), flops + 30.0 * npx)) {
                         head_in_conv.done = true;
                         break;
                     }
@@ -609,6 +611,10 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     int Cin = o.inA.d.C + o.inB.d.C;
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d));
                     double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
+                    if (tail_done == &o && head_was_in_conv) {      // its backward ran with the head, inside the forward pass (fast_tail3)
+                        tail_done = nullptr;
+                        break;
+                    }
                     if (!generic && (fast_conv_bwd(this, B, o, ob, ib, flops) || fast_first_conv_bwd(this, B, o, ob, ib, flops) ||
                                      ig_conv_bwd(this, B, o, ob, ib, flops))) break;
                     if (!all_f32(o)) return DNNCA_ESTATE;

@@ -1,0 +1,381 @@
+// strip_dev.h -- "column strip" kernels for the 3-channel, full-resolution level of configs/unet.yaml (device code; included by
+// kernels_mfma.hip, which owns the launch plan).
+//
+// The 512^2 level moves 25 MB per tensor and the step was paying for each of them several times over: conv forward writes the
+// feature map, the head reads it and writes its gradient, the conv backward reads that gradient and the conv input again ...
+// Every one of those passes ran at the speed of a cold HBM copy (~3-4 TB/s): the step is bound by bytes and launches, not by
+// arithmetic.  These kernels remove passes by CHAINING layers inside one wave:
+//
+//   one wave = a strip of 64 pixel columns (60 owned + 2 halo columns on each side), walked top to bottom over a chunk of rows;
+//   a lane owns one pixel column.  Everything a lane needs from its horizontal neighbours comes from the adjacent lanes by DPP
+//   wave shifts; vertical neighbours are the rows the wave has just walked over (rotating three-row windows in registers).
+//   No LDS tile, no workgroup barrier, no staging pass: the only memory traffic is each lane's own 12 bytes per tensor row,
+//   PFD rows in flight, through buffer loads / stores whose out-of-range lanes read zeros / drop the store (zero padding, strip
+//   and chunk edges cost no branches, and hipcc counts its s_waitcnt vmcnt(N) exactly: straight-line vector memory traffic).
+//   The 81 conv weights are scalar-register operands of the FMAs.
+//
+// k_tail3: the conv that feeds the annotator head, in a train step -- conv forward (+ activation), the 1x1 head, the weighted BCE
+//   (unet.py:241-244, losses.py:17-37), the head's backward and the conv's whole backward (data, weight and bias gradient) in ONE
+//   pass: reads the conv input and the labels, writes the gradient of the conv input.  The feature map, the logits and their
+//   gradients never exist in memory (4 of 7 full-resolution tensor passes of the two launches it replaces).
+#pragma once
+#include <type_traits>
+
+namespace dnnca {
+
+typedef float f3 __attribute__((ext_vector_type(3)));
+
+constexpr int STRIP = 60;                       // owned pixel columns per wave
+constexpr unsigned STRIP_HALF = 0x40000000u;    // "not there" part of a byte offset: past every buffer (their sizes are below it), and
+                                                // the sum of two of them still is (no wrap-around): loads give 0, stores are dropped
+constexpr unsigned STRIP_RSRC = 0x00020000u;    // raw buffer, 32-bit data format
+
+// lane l <- lane l - 1 (lane 0 <- 0) / lane l <- lane l + 1 (lane 63 <- 0)
+__device__ __forceinline__ float from_left(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+// one row of a lane's 3 x 3 x 3 window: [left pixel | own pixel | right pixel] x 3 channels
+// SHIFT: 0 = DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1 -- measured at the price of ~6 FMAs each), 1 = the LDS crossbar
+// (ds_bpermute_b32: no LDS memory, runs beside the vector ALU; la / ra = byte addresses of the left / right neighbour lane),
+// 2 = none (tuning builds)
+template <int SHIFT = 0>
+__device__ __forceinline__ void strip_expand(const float (&v)[3], float (&o)[9], int la = 0, int ra = 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (SHIFT == 0) {
+            o[c] = from_left(v[c]);
+            o[6 + c] = from_right(v[c]);
+        } else if (SHIFT == 1) {
+            o[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(la, __builtin_bit_cast(int, v[c])));
+            o[6 + c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ra, __builtin_bit_cast(int, v[c])));
+        } else {
+            o[c] = v[c] * 0.5f;
+            o[6 + c] = v[c] * 0.25f;
+        }
+        o[3 + c] = v[c];
+    }
+}
+__device__ __forceinline__ f3 strip_load3(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0));
+}
+
+struct TailArgs {
+    const float* x;          // conv input [B, H, W, 3]
+    const float* w;          // conv kernel, HWIO (81 floats), and bias
+    const float* bias;
+    float alpha;             // slope of the conv's activation (< 0: none)
+    const float* hy;         // labels [B, H, W]
+    const float* hw;         // head kernel (3) and bias
+    const float* hb;
+    float* hpartials;        // [gridDim.x][5] block partial sums (head dW (3), db, loss), reduced by k_pg_fold
+    double* hscalars;        // scalars[0] = label sum, or, with hlabel_part: written by block 0
+    const float* hlabel_part;  // [hlabel_nblk][4] per-block (sum, min, max, -) of the labels from the first encoder block's launch
+    int hlabel_nblk;
+    dnnca_loss_cfg hcfg;
+    double hn_label;
+    float hgscale;
+    int hmask;               // the head's gradient is multiplied by act'(feature map)
+    float halpha;
+    float* dx;               // gradient of the conv input [B, H, W, 3]
+    int mask;                // ... multiplied by act'(x)
+    float mask_alpha;
+    float* slabs;            // weight-gradient partial sums [NBUCKET][4*256] (k_pg_fold layout)
+    int B, H, W;
+    int nstrips, nchunks;    // strips of STRIP columns; row chunks per image
+};
+
+template <int PFD, int WSCALAR, bool MIDBAR, int ABL = 0, int SHIFT = 0>      // ABL (tuning builds): bit mask of parts left out
+__global__ __launch_bounds__(256, 2) void k_tail3(TailArgs p) {
+    static_assert(PFD == 6 || PFD == 3, "the row loop is unrolled lcm(3 window slots, PFD prefetch slots) times");
+    constexpr int NACC = 84, NH = 5, NRED = NACC + NH, WRw = 18, MT = 4, NBK = 32;      // slab geometry of k_pgbwd<3,1,3>
+    __shared__ float red[4 * NRED + 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- this wave's task: blocks b, b + 8, ... share an XCD (and its L2): each XCD gets one contiguous eighth of the task list;
+    // consecutive tasks are the adjacent strips of one row chunk (whole image rows are in flight together).  A wave past the end
+    // of the list repeats the last task and owns nothing.
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ntasks = p.B * p.nchunks * p.nstrips;
+    const int t0 = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
+    const int t = t0 < ntasks ? t0 : ntasks - 1;
+    const int strip = t % p.nstrips, ck = (t / p.nstrips) % p.nchunks, b = t / (p.nstrips * p.nchunks);
+    const int r0 = (int)((long long)ck * p.H / p.nchunks), r1 = (int)((long long)(ck + 1) * p.H / p.nchunks);
+    const int c = strip * STRIP - 2 + lane;
+    const bool col_ok = (unsigned)c < (unsigned)p.W;
+    const bool lane_own = lane >= 2 && lane < 2 + STRIP && col_ok && t0 < ntasks;
+    const unsigned npix = (unsigned)p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, npix * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)p.hy, 0, npix * 4u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, npix * 12u, STRIP_RSRC);
+    // A byte offset = (per-lane column part) + (per-row part, uniform).  Whatever is not there -- a column outside the image or
+    // the strip, a row outside the image or the chunk -- contributes STRIP_HALF instead: the sum then lies past the buffer
+    // (buffers are smaller than STRIP_HALF), the load returns zeros and the store is dropped.  No predicates, no branches.
+    unsigned colx = col_ok ? (unsigned)c * 12u : STRIP_HALF, coll = col_ok ? (unsigned)c * 4u : STRIP_HALF;
+    unsigned cold = lane_own ? (unsigned)c * 12u : STRIP_HALF;
+    float colf = col_ok ? 1.0f : 0.f, ownf = lane_own ? 1.0f : 0.f;
+    int la = ((lane + 63) & 63) * 4, ra = ((lane + 1) & 63) * 4;      // neighbour lanes (the wrap-around lands in halo lanes)
+    asm volatile("" : "+v"(colx), "+v"(coll), "+v"(cold), "+v"(colf), "+v"(ownf), "+v"(la), "+v"(ra));
+    const unsigned img0 = (unsigned)b * p.H;                  // first row of this image, counted through the batch
+    // (uniform row conditions as bit masks: as `cond ? a : b` hipcc turned them into branches around duplicated loads, with
+    //  s_waitcnt vmcnt(0) on the joins)
+    auto inside = [](int row, int lo, int hi) -> unsigned {                  // all ones when lo <= row < hi
+        return ~(unsigned)(((row - lo) | (hi - 1 - row)) >> 31);
+    };
+    auto rowpart = [&](int row, unsigned ok, unsigned bytes) -> unsigned {   // uniform
+        return ((img0 + (unsigned)row) * (unsigned)p.W * bytes & ok) | (STRIP_HALF & ~ok);
+    };
+    auto fmask = [](float v, unsigned m) -> float { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m); };
+
+    // ---- everything the kernel waits for at its start is issued up front: the first rows of the strip, the weights, the label
+    // statistics (three dependent memory round trips otherwise)
+    f3 xp[PFD];
+    unsigned lp[PFD];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) {
+        const int row = r0 - 2 + k;
+        const unsigned ok = inside(row, 0, p.H);
+        xp[k] = strip_load3(rsx, colx + rowpart(row, ok, 12u));
+        lp[k] = __builtin_amdgcn_raw_buffer_load_b32(rsy, coll + rowpart(row, ok, 4u), 0, 0);
+    }
+    // the 81 weights: the first kernel row as scalar-register operands, the other two rows in vector registers (all 81 as scalars
+    // plus three buffer descriptors overflow the scalar file: 150 spills, a v_readlane in front of every third FMA); the rarely
+    // used uniforms live in vector registers as well
+    float w[81];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) w[i] = p.w[i];
+    float hwv[3] = {p.hw[0], p.hw[1], p.hw[2]}, hbias = p.hb[0], bs[3] = {p.bias[0], p.bias[1], p.bias[2]};
+
+    // ---- this step's positive-class weight (losses.py:24-29) from the label statistics
+    float hwgt;
+    {
+        double lsum;
+        if (p.hlabel_part) {
+            double ds = 0.0;
+            float mn = INFINITY, mx = -INFINITY;
+            for (int i = tid; i < p.hlabel_nblk; i += 256) {
+                const float4 v = reinterpret_cast<const float4*>(p.hlabel_part)[i];
+                ds += (double)v.x;
+                mn = fminf(mn, v.y);
+                mx = fmaxf(mx, v.z);
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                ds += __shfl_down(ds, o, 64);
+                mn = fminf(mn, __shfl_down(mn, o, 64));
+                mx = fmaxf(mx, __shfl_down(mx, o, 64));
+            }
+            double* redd = reinterpret_cast<double*>(red);
+            float* redf = red + 8;
+            if (lane == 0) { redd[wave] = ds; redf[wave] = mn; redf[4 + wave] = mx; }
+            __syncthreads();
+            ds = 0.0; mn = INFINITY; mx = -INFINITY;
+            for (int k = 0; k < 4; ++k) { ds += redd[k]; mn = fminf(mn, redf[k]); mx = fmaxf(mx, redf[4 + k]); }
+            __syncthreads();
+            lsum = ds;
+            if (blockIdx.x == 0 && tid == 0) { p.hscalars[0] = ds; p.hscalars[1] = (double)mn; p.hscalars[2] = (double)mx; }
+        } else {
+            lsum = p.hscalars[0];
+        }
+        if (p.hcfg.has_weight) {
+            hwgt = p.hcfg.weight;
+        } else {
+            const float pr = (float)(lsum / p.hn_label);
+            hwgt = pr > 0.f ? 1.0f / pr : 1.0f;
+        }
+        hwgt = p.hcfg.weight_mul * hwgt + p.hcfg.weight_add;
+    }
+    float hslope = p.hmask ? p.halpha : 1.0f, xslope = p.mask ? p.mask_alpha : 1.0f, gsc = p.hgscale;
+    float aslope = p.alpha < 0.f ? 1.0f : p.alpha, hwgt1 = hwgt - 1.0f;
+    // (nothing pending from here on: hipcc's vmcnt counts inside the row loop are then the exact steady-state ones -- it otherwise
+    //  merges the prologue's order of operations in and waits for loads that have just been issued.  As the builtin, so that its
+    //  wait counting sees it)
+    __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0) lgkmcnt(0)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) asm volatile("" : "+v"(hwv[cc]), "+v"(bs[cc]));
+    asm volatile("" : "+v"(hbias), "+v"(hwgt1), "+v"(hslope), "+v"(xslope), "+v"(gsc), "+v"(aslope));
+#pragma unroll
+    for (int i = 0; i < 81; ++i) {
+        if (i < WSCALAR) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[i])));
+        else asm volatile("" : "+v"(w[i]));
+    }
+
+    float acc[NACC], hsum[NH];    // acc[((wy*3 + wx)*3 + ci)*3 + co] = dW[2-wy][2-wx][ci][co], acc[81 + co] = db[co]; hsum = head dW, db, loss
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) hsum[i] = 0.f;
+    float xw[3][9], dzw[3][9], lab_prev = 0.f;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { xw[s][i] = 0.f; dzw[s][i] = 0.f; }
+
+    // One step of the walk.  Step s (u = s mod PFD, compile time) takes x row i = r0 - 2 + s out of the prefetch ring, then runs
+    // the conv forward + head of row i - 1 (FWD) and the conv backward of row i - 2 (BWD).  The first steps of a chunk only fill
+    // the windows: steps 0, 1 run neither, steps 2, 3 no backward.
+    auto step = [&](auto uc, auto fwdc, auto bwdc, int i) {
+        constexpr int u = decltype(uc)::value;
+        constexpr bool FWD = decltype(fwdc)::value, BWD = decltype(bwdc)::value;
+        // ---- x row i (and its labels) out of the prefetch ring; the slot takes row i + PFD
+        // (the slot is refilled only after its last reader, and the values leave it through real copies: a value that is still
+        //  live when its slot's next load is issued gets a second register, and the copies hipcc then places on the loop's back
+        //  edge wait for the loads that have just been issued -- a memory round trip per iteration)
+        float xo[3], lab_i;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) asm volatile("v_mov_b32 %0, %1" : "=v"(xo[c3]) : "v"(xp[u][c3]));
+        strip_expand<(ABL & 16) ? 2 : SHIFT>(xo, xw[u % 3], la, ra);                      // window slots: row i-2 -> (u+1)%3, i-1 -> (u+2)%3, i -> u%3
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lab_i) : "v"(lp[u]));
+        {
+            const int row = i + PFD;
+            const unsigned ok = inside(row, 0, p.H);
+            xp[u] = strip_load3(rsx, colx + rowpart(row, ok, 12u));
+            lp[u] = __builtin_amdgcn_raw_buffer_load_b32(rsy, coll + rowpart(row, ok, 4u), 0, 0);
+        }
+        if constexpr (FWD) {
+            // ---- conv forward of row i - 1, activation, head, weighted BCE, head backward -> dz of row i - 1
+            // (two partial sums per output channel: six independent FMA chains -- with three, a wave's next FMA waits for the
+            //  previous one of its chain: 1.7 instead of 1.1 ns per FMA, tools/micro/valu_dep.hip)
+            const int rf = i - 1;
+            float f[3] = {bs[0], bs[1], bs[2]}, f2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < ((ABL & 1) ? 1 : 3); ++dy)
+#pragma unroll
+                for (int k = 0; k < ((ABL & 1) ? 3 : 9); ++k) {
+                    const float xv = xw[(u + 1 + dy) % 3][k];
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        if ((dy * 9 + k) & 1) f2[co] = fmaf(xv, w[(dy * 9 + k) * 3 + co], f2[co]);
+                        else f[co] = fmaf(xv, w[(dy * 9 + k) * 3 + co], f[co]);
+                    }
+                }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                f[co] += f2[co];
+                f[co] = fmaxf(f[co], f[co] * aslope);       // aslope in [0, 1] (1: no activation)
+            }
+            // imgf: a pixel of the image (else: the zero padding of dz); ownm: ... that this wave counts
+            const float imgf = fmask(colf, inside(rf, 0, p.H));
+            const float ownm = fmask(ownf, inside(rf, r0, r1));
+            const float z = lab_prev;
+            float xl = hbias;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) xl = fmaf(f[co], hwv[co], xl);
+            const float mk = fmaf(z, hwgt1, 1.0f);
+            // e = exp(-|x|) in (0, 1]; sigmoid and log(1 + e) from the hardware exp2 / log2 / rcp (1 ulp each; 1 + e is exact to
+            // 6e-8, far below the float32 noise of the 2M-term loss sum)
+            const float e = (ABL & 8) ? 0.5f : __builtin_amdgcn_exp2f(-1.44269504f * fabsf(xl));
+            const float r1e = (ABL & 8) ? 0.66f : __builtin_amdgcn_rcpf(1.0f + e);
+            const float sig = xl >= 0.f ? r1e : e * r1e;
+            const float dl = mk * (sig - z) * gsc * imgf;
+            const float dlo = dl * ownm;
+            hsum[4] = fmaf(fmaxf(xl, 0.f) - xl * z + 0.693147181f * ((ABL & 8) ? 0.58f : __builtin_amdgcn_logf(1.0f + e)), mk * ownm, hsum[4]);
+            hsum[3] += dlo;
+            float dz[3];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                hsum[co] = fmaf(f[co], dlo, hsum[co]);
+                dz[co] = dl * hwv[co] * (f[co] > 0.f ? 1.0f : hslope);
+            }
+            if constexpr (MIDBAR) __builtin_amdgcn_sched_barrier(0);      // keep the forward and the backward halves of a step apart
+            strip_expand<(ABL & 16) ? 2 : SHIFT>(dz, dzw[u % 3], la, ra);                     // dz window slots: row j-1 -> (u+1)%3, j -> (u+2)%3, j+1 -> u%3
+        }
+        lab_prev = lab_i;
+        if constexpr (BWD) {
+            // ---- conv backward of row j = i - 2: data gradient, weight gradient, bias gradient from the dz window
+            const int j = i - 2;
+            const unsigned rowj = inside(j, r0, r1);          // uniform
+            const float ownj = fmask(ownf, rowj);
+            const float xc[3] = {xw[(u + 1) % 3][3], xw[(u + 1) % 3][4], xw[(u + 1) % 3][5]};
+            const float xv[3] = {xc[0] * ownj, xc[1] * ownj, xc[2] * ownj};
+            float dx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int wy = 0; wy < 3; ++wy)
+#pragma unroll
+                for (int wx = 0; wx < 3; ++wx)
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        const float d = dzw[(u + 1 + wy) % 3][wx * 3 + co];
+#pragma unroll
+                        for (int ci = 0; ci < 3; ++ci) {
+                            if (!(ABL & 2) || (wy == 1 && wx == 1)) dx[ci] = fmaf(d, w[(((2 - wy) * 3 + (2 - wx)) * 3 + ci) * 3 + co], dx[ci]);
+                            if (!(ABL & 4) || (wy == 1 && wx == 1))
+                                acc[((wy * 3 + wx) * 3 + ci) * 3 + co] = fmaf(xv[ci], d, acc[((wy * 3 + wx) * 3 + ci) * 3 + co]);
+                        }
+                    }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) acc[81 + co] = fmaf(dzw[(u + 2) % 3][3 + co], ownj, acc[81 + co]);
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) dx[ci] *= xc[ci] > 0.f ? 1.0f : xslope;
+            const f3 dv = {dx[0], dx[1], dx[2]};
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b96(rsd, 0, 0, 0)), dv), rsd,
+                                                  cold + rowpart(j, rowj, 12u), 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using Yes = std::true_type;
+    using No = std::false_type;
+    const int nsteps = r1 - r0 + 4;
+    int s0 = 0;
+    if constexpr (PFD == 3) {
+        // the first two groups, specialised: steps 0, 1 fill the x window; 2, 3 add the forward pass; from 4 on the whole step
+        step(I0{}, No{}, No{}, r0 - 2);
+        step(I1{}, No{}, No{}, r0 - 1);
+        step(I2{}, Yes{}, No{}, r0);
+        step(I0{}, Yes{}, No{}, r0 + 1);
+        step(I1{}, Yes{}, Yes{}, r0 + 2);
+        step(I2{}, Yes{}, Yes{}, r0 + 3);
+        s0 = 6;
+    }
+#pragma unroll 1
+    for (; s0 < nsteps; s0 += PFD) {
+        step(I0{}, Yes{}, Yes{}, r0 - 2 + s0);
+        step(I1{}, Yes{}, Yes{}, r0 - 1 + s0);
+        step(I2{}, Yes{}, Yes{}, r0 + s0);
+        if constexpr (PFD == 6) {
+            step(std::integral_constant<int, 3>{}, Yes{}, Yes{}, r0 + 1 + s0);
+            step(std::integral_constant<int, 4>{}, Yes{}, Yes{}, r0 + 2 + s0);
+            step(std::integral_constant<int, 5>{}, Yes{}, Yes{}, r0 + 3 + s0);
+        }
+    }
+    // ---- lane sums by DPP, the four waves through LDS; weight gradient: one atomic per element into slab (blockIdx % NBUCKET), laid
+    // out where k_pg_fold expects D[(dy, j), (dx, co)] (everything in the dx = 0 entries, the bias in the all-ones row); head: one row
+    // of the partials table per block
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        const float s = wave_total_l63(acc[i]);
+        if (lane == 63) red[wave * NRED + i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const float s = wave_total_l63(hsum[i]);
+        if (lane == 63) red[wave * NRED + NACC + i] = s;
+    }
+    __syncthreads();
+    if (tid < NRED) {
+        const int e = tid;
+        const float v = (red[e] + red[NRED + e]) + (red[2 * NRED + e] + red[3 * NRED + e]);
+        if (e < NACC) {
+            int mrow, co;
+            if (e < 81) {
+                const int tap = e / 9, ci = (e / 3) % 3;
+                co = e % 3;
+                mrow = (2 - tap / 3) * WRw + (2 - tap % 3) * 3 + ci;
+            } else {
+                mrow = 3 * WRw;
+                co = e - 81;
+            }
+            atomicAdd(p.slabs + (size_t)(blockIdx.x % NBK) * (MT * 256) + slab_index(mrow, co), v);
+        } else {
+            p.hpartials[blockIdx.x * NH + (e - NACC)] = v;
+        }
+    }
+}
+
+}  // namespace dnnca

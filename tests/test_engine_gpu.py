@@ -146,7 +146,7 @@ def test_full_size_label_statistics_ride_in_the_first_block(gpu):
     m = gpu.DeviceModel('unet', 1, H, W, B, **UNET)
     m.init_glorot(seed=2)
     names = [r[0] for r in m.plan()]
-    assert 'pgfwd_head_3x1_3' in names and 'fz_down_1_3' in names and 'label_stats4' not in names and 'head_train_3' not in names
+    assert 'tail3_3x1_3' in names and 'fz_down_1_3' in names and 'label_stats4' not in names and 'head_train_3' not in names
     cfg = m.loss_cfg(weight_mul=3.0, weight_add=0.25)
     out = m.train_step(x, y, 0.0, cfg)
     pr = float(y.astype(np.float64).mean())
@@ -440,12 +440,16 @@ def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
     m.close()
 
 
-@pytest.mark.parametrize('B, H, W', [(2, 40, 128), (8, 16, 256)])
-def test_vector_alu_backward_of_the_3_channel_level_against_oracle(gpu, B, H, W):
-    """configs/unet.yaml on images whose first level is made of whole 128 x 8 tiles: the single-source 3 -> 3 channel convs of
-    that level then run the all-vector-ALU backward kernel (k_bwd3v: data + weight + bias gradient from one register window,
-    with and without the folded max-pool backward) -- against the float64 oracle, every variable on its own scale.  The second
-    shape has a tile count divisible by 8 (the XCD-aware tile order)."""
+@pytest.mark.parametrize('B, H, W, tail', [(2, 40, 128, True), (8, 16, 256, True), (2, 40, 128, False), (8, 16, 256, False),
+                                           (3, 24, 200, True), (1, 72, 64, True)])
+def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypatch, B, H, W, tail):
+    """configs/unet.yaml, the vector-ALU kernels of the full-resolution 3-channel level against the float64 oracle, every variable on
+    its own scale.  tail: the conv that feeds the head runs forward + head + loss + its whole backward in one column-strip launch
+    (k_tail3: strips of 60 columns, row chunks; shapes with partial strips, one strip, chunk counts not divisible by 8).  Without it
+    and on images made of whole 128 x 8 tiles that conv's backward is the tile kernel k_bwd3v (also behind the first encoder block,
+    with the folded max-pool backward); the (8, 16, 256) shape has a tile count divisible by 8 (the XCD-aware tile order)."""
+    if not tail:
+        monkeypatch.setenv('DNNCA_NO_TAIL3', '1')
     spec = O.ModelSpec('unet', 1, **UNET)
     params = Hp.perturbed_params(spec, np.float64)
     rng = np.random.default_rng(13)
@@ -463,8 +467,9 @@ def test_vector_alu_backward_of_the_3_channel_level_against_oracle(gpu, B, H, W)
     floor = [10 * np.abs(g32[sl] - gref[sl]).max() for _, sl in Hp.tensor_slices(spec)]
     Hp.assert_grads_per_tensor(spec, m.get_grads(), gref, 2e-5, floor=floor)
     plan = set(r[0] for r in m.plan())
-    assert 'bwd3v_3x1_3' in plan, plan
-    assert 'bwd3v_pool_3x1_3' in plan or not any(k.startswith('fz_down') for k in plan), plan
+    assert ('tail3_3x1_3' if tail else 'bwd3v_3x1_3') in plan, plan
+    if W % 128 == 0:
+        assert 'bwd3v_pool_3x1_3' in plan or not any(k.startswith('fz_down') for k in plan), plan
     m.close()
 
 
