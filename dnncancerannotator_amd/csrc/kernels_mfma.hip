@@ -1605,6 +1605,24 @@ bool fast_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* pool)
     return false;
 }
 
+// The first conv of the network when `conv` is the second conv of the first encoder block and the pair can run its backward in
+// one column-strip launch (k_first3, strip_dev.h); nullptr otherwise.
+static Op* first3_conv0(Model* m, Op& conv) {
+    if (getenv("DNNCA_NO_FIRST3")) return nullptr;
+    const size_t i = (size_t)(&conv - m->ops.data());
+    if (i < 1 || i >= m->ops.size()) return nullptr;
+    Op& c0 = m->ops[i - 1];
+    if (c0.type != OP_CONV || c0.need_din || c0.inB.d.C || c0.inA.d.C != 1 || c0.out.d.C != 3 || c0.k != 3 || c0.out.d.p != conv.inA.d.p) return nullptr;
+    if (!conv_supported(m, c0) || !conv_supported(m, conv) || conv.inB.d.C || conv.inA.d.C != 3 || conv.out.d.C != 3 || conv.accA) return nullptr;
+    if (!dense(c0.inA.d) || !dense(conv.inA.d) || !dense(conv.out.d) || !dense(conv.out.g) || (c0.alpha >= 0.f && !c0.premasked)) return nullptr;
+    if ((c0.alpha >= 0.f) != (conv.maskA != 0)) return nullptr;       // the activation derivative of the first conv rides in this launch
+    const int H = conv.out.d.H, W = conv.out.d.W;
+    if ((H & 1) || (W & 1) || W < 8 || H < 8 || (double)m->desc.max_batch * H * W * 12.0 >= 1073741824.0) return nullptr;
+    PgPlan& pl = g_plans[m];
+    if (pl.wslot.find({&c0, 0}) == pl.wslot.end() || pl.wslot.find({&conv, 0}) == pl.wslot.end()) return nullptr;
+    return &c0;
+}
+
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops) {
     if (!conv_supported(m, o)) return false;
     PgPlan& pl = g_plans[m];
@@ -1650,6 +1668,34 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
     const double bytes = out_bytes + (o.need_din ? 2 : 1) * in_bytes;
     const double fl = (o.need_din ? 2 : 1) * flops;
     // single-source 3 -> 3 channels: the all-vector-ALU backward (k_bwd3v), with or without the pool fold
+    // the first encoder block: the second conv's backward (with the pool fold) and the first conv's weight gradient in one launch
+    if (m->pool_fold.conv == &o) {
+        if (Op* c0 = first3_conv0(m, o)) {
+            const Op& pool = *m->pool_fold.pool;
+            m->pool_fold.conv = nullptr;
+            FirstArgs f{};
+            f.dskip = o.out.g.p; f.y1 = o.out.d.p;
+            f.dpool = pool.out.g.p; f.idx = pool.pool_idx;
+            f.x1 = o.inA.d.p; f.xin = c0->inA.d.p;
+            f.w = m->p + o.w_off;
+            f.pf_alpha = pool.mask_alpha;
+            f.mask = o.maskA; f.mask_alpha = o.mask_alpha;
+            f.slabs1 = a.slabs[0];
+            f.slabs0 = pl.slabs + pl.folds[pl.wslot.find({c0, 0})->second].slab_off;
+            f.B = B; f.H = a.H; f.W = a.W;
+            f.nstrips = (a.W + STRIP - 1) / STRIP;
+            int nchunks = 2048 / (B * f.nstrips);
+            if (nchunks > a.H / 8) nchunks = a.H / 8;
+            if (nchunks < 1) nchunks = 1;
+            f.nchunks = nchunks;
+            const int nblk = (B * nchunks * f.nstrips + 3) / 4;
+            const double npx = (double)B * a.H * a.W;
+            LAUNCH(m, "first3_bwd", 4.0 * npx * (3 + 3 + 3 + 1 + 0.75) + 0.75 * npx, 2.0 * npx * (162 + 30),
+                   hipLaunchKernelGGL((k_first3<2, 40>), dim3(nblk), dim3(256), 0, m->stream, f));
+            m->first_done = c0;
+            return true;
+        }
+    }
     static const bool v3_on = getenv("DNNCA_NO_BWD3V") == nullptr;
     if (v3_on && o.need_din && C == 3 && CO == 3 && NS == 1 && !o.accA && a.W % 128 == 0 && a.H % TH == 0) {
         const bool pf = m->pool_fold.conv == &o;
@@ -1756,7 +1802,8 @@ bool fast_pool_fold(Model* m, Op& pool, Op& conv) {
     const int C = conv.inA.d.C, CO = conv.out.d.C;
     if (C != CO || !(C == 3 || C == 6 || C == 12)) return false;
     const int TW = 32 * (12 / CO);
-    if (conv.out.d.W % TW || conv.out.d.H % TH || !dense(pool.out.g) || !dense(pool.out.d)) return false;
+    if (!dense(pool.out.g) || !dense(pool.out.d)) return false;
+    if ((conv.out.d.W % TW || conv.out.d.H % TH) && !first3_conv0(m, conv)) return false;      // the tile kernels fold whole tiles only
     pool.pool_idx_valid = false;
     m->pool_fold.conv = &conv;
     m->pool_fold.pool = &pool;

@@ -386,7 +386,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
     DN_TRY(fast_prepare(this));
     DN_TRY(ig_prepare(this));
     head_in_conv.done = false;
-    tail_done = nullptr;
+    tail_done = first_done = nullptr;
     // the head will ride in the last conv's epilogue: it needs the label statistics (positive rate) of this step, so they go first
     // (pg_prep has just zeroed the scalars)
     bool head_in_conv_ok = head_in_conv.requested && !generic && (step_init_done || dry) && head_defer_ok && ops.size() >= 2 &&
@@ -611,6 +611,10 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                     int Cin = o.inA.d.C + o.inB.d.C;
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.inB.d));
                     double flops = 2.0 * B * o.out.d.H * o.out.d.W * o.k * o.k * Cin * o.out.d.C;
+                    if (first_done == &o) {                         // its weight gradient rode in the previous launch (k_first3)
+                        first_done = nullptr;
+                        break;
+                    }
                     if (tail_done == &o && head_was_in_conv) {      // its backward ran with the head, inside the forward pass (fast_tail3)
                         tail_done = nullptr;
                         break;

@@ -378,4 +378,224 @@ __global__ __launch_bounds__(256, 2) void k_tail3(TailArgs p) {
     }
 }
 
+// k_first3: the backward of the first encoder block in one pass -- the second conv's whole backward with the max-pool's backward
+// folded into its staging (dz = (skip gradient + pooled gradient at the recorded window position) * act'(y), components.py:54) AND the
+// first conv's weight / bias gradient (its input gradient is needed by nobody: it reads the network input).  The gradient of the
+// first conv's output never exists in memory: 25 MB less written, 25 MB less read and one launch less than k_bwd3v<PF> followed by the
+// weight-gradient pass of the 1 -> 3 channel conv.  Reads per row and lane: skip gradient, conv output, pooled gradient + position,
+// conv input (12 bytes each), network input (4 bytes); writes nothing but the two sets of weight-gradient slabs.
+struct FirstArgs {
+    const float* dskip;      // gradient of the second conv's output from the skip connection [B, H, W, 3]
+    const float* y1;         // the second conv's output [B, H, W, 3]
+    const float* dpool;      // gradient of the pooled tensor [B, H/2, W/2, 3]
+    const unsigned char* idx;  // window position of every pooled maximum [B, H/2, W/2, 3]
+    const float* x1;         // the second conv's input = the first conv's output [B, H, W, 3]
+    const float* xin;        // network input [B, H, W, 1]
+    const float* w;          // the second conv's kernel, HWIO (81 floats)
+    float pf_alpha;          // slope of act'(y1)
+    int mask;                // the first conv's activation: the gradient of its output is multiplied by act'(x1)
+    float mask_alpha;
+    float* slabs1;           // weight-gradient slabs of the second conv [NBUCKET][4*256] (k_pgbwd<3,1,3> geometry)
+    float* slabs0;           // ... of the first conv [NBUCKET][2*256] (k_pgbwd<1,1,3> geometry: window row of 6 floats)
+    int B, H, W;
+    int nstrips, nchunks;
+};
+
+template <int PFD, int WSCALAR>
+__global__ __launch_bounds__(256, 2) void k_first3(FirstArgs p) {
+    static_assert(PFD == 3 || PFD == 2, "ring slots; the row loop is unrolled 6 times (3 window slots x 2)");
+    constexpr int NA1 = 84, NA0 = 30, NRED = NA1 + NA0, NBK = 32;
+    __shared__ float red[4 * NRED];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ntasks = p.B * p.nchunks * p.nstrips;
+    const int t0 = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
+    const int t = t0 < ntasks ? t0 : ntasks - 1;
+    const int strip = t % p.nstrips, ck = (t / p.nstrips) % p.nchunks, b = t / (p.nstrips * p.nchunks);
+    const int r0 = (int)((long long)ck * p.H / p.nchunks), r1 = (int)((long long)(ck + 1) * p.H / p.nchunks);
+    const int c = strip * STRIP - 2 + lane;
+    const bool col_ok = (unsigned)c < (unsigned)p.W;
+    const bool lane_own = lane >= 2 && lane < 2 + STRIP && col_ok && t0 < ntasks;
+    const unsigned npix = (unsigned)p.B * p.H * p.W, Hp = p.H >> 1, Wp = p.W >> 1, npool = (unsigned)p.B * Hp * Wp;
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.dskip, 0, npix * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)p.y1, 0, npix * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, npix * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)p.xin, 0, npix * 4u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void*)p.dpool, 0, npool * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)p.idx, 0, npool * 3u, STRIP_RSRC);
+    // byte offset = column part (per lane) + row part (uniform); what is not there contributes STRIP_HALF (see k_tail3)
+    unsigned col12 = col_ok ? (unsigned)c * 12u : STRIP_HALF, col4 = col_ok ? (unsigned)c * 4u : STRIP_HALF;
+    unsigned colp12 = col_ok ? (unsigned)(c >> 1) * 12u : STRIP_HALF, colp3 = col_ok ? (unsigned)(c >> 1) * 3u : STRIP_HALF;
+    float ownf = lane_own ? 1.0f : 0.f;
+    int la = ((lane + 63) & 63) * 4, ra = ((lane + 1) & 63) * 4, cpar = c & 1;
+    asm volatile("" : "+v"(col12), "+v"(col4), "+v"(colp12), "+v"(colp3), "+v"(ownf), "+v"(la), "+v"(ra), "+v"(cpar));
+    const unsigned img0 = (unsigned)b * p.H, imgp0 = (unsigned)b * Hp;
+    auto inside = [](int row, int lo, int hi) -> unsigned { return ~(unsigned)(((row - lo) | (hi - 1 - row)) >> 31); };
+    auto rowpart = [&](unsigned row0, int row, unsigned ok, unsigned rowbytes) -> unsigned {   // uniform
+        return ((row0 + (unsigned)row) * rowbytes & ok) | (STRIP_HALF & ~ok);
+    };
+    auto fmask = [](float v, unsigned m) -> float { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m); };
+
+    // ring slot k: what step s (s mod PFD == k) consumes -- rows i = r0 - 1 + s of dskip / y1 / dpool / idx / xin, row i - 1 of x1
+    f3 gq[PFD], yq[PFD], pq[PFD], xq[PFD];
+    unsigned kq[PFD][3], iq[PFD];
+    auto issue = [&](auto kc, int i) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned ok = inside(i, 0, p.H), okx = inside(i - 1, 0, p.H);
+        const unsigned r12 = rowpart(img0, i, ok, (unsigned)p.W * 12u);
+        gq[k] = strip_load3(rsg, col12 + r12);
+        yq[k] = strip_load3(rsy, col12 + r12);
+        xq[k] = strip_load3(rsx, col12 + rowpart(img0, i - 1, okx, (unsigned)p.W * 12u));
+        iq[k] = __builtin_amdgcn_raw_buffer_load_b32(rsi, col4 + rowpart(img0, i, ok, (unsigned)p.W * 4u), 0, 0);
+        pq[k] = strip_load3(rsp, colp12 + rowpart(imgp0, i >> 1, ok, Wp * 12u));
+        const unsigned o3 = colp3 + rowpart(imgp0, i >> 1, ok, Wp * 3u);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) kq[k][ch] = __builtin_amdgcn_raw_buffer_load_b8(rsk, o3 + ch, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    issue(I0{}, r0 - 1);
+    issue(I1{}, r0);
+    if constexpr (PFD == 3) issue(I2{}, r0 + 1);
+    float w[81];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) w[i] = p.w[i];
+    float yslope = p.pf_alpha, xslope = p.mask ? p.mask_alpha : 1.0f;
+    __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0) lgkmcnt(0): nothing pending at the loop's entry (see k_tail3)
+    asm volatile("" : "+v"(yslope), "+v"(xslope));
+#pragma unroll
+    for (int i = 0; i < 81; ++i) {
+        if (i < WSCALAR) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[i])));
+        else asm volatile("" : "+v"(w[i]));
+    }
+    float acc[NA1], acc0[NA0];    // acc as in k_tail3; acc0[(dy*3 + kx)*3 + co] = dW0[dy][kx][0][co], acc0[27 + co] = db0[co]
+#pragma unroll
+    for (int i = 0; i < NA1; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA0; ++i) acc0[i] = 0.f;
+    float dzw[3][9], iw[3][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dzw[s][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) iw[s][i] = 0.f;
+    }
+    // step s (u = s mod 6): rows i = r0 - 1 + s arrive -> dz of row i, network-input row i into the windows (slot u % 3);
+    // backward of row j = i - 1 (BWD: not in the first two steps of a chunk)
+    auto step = [&](auto uc, auto bwdc, int i) {
+        constexpr int u = decltype(uc)::value, k = u % PFD;
+        constexpr bool BWD = decltype(bwdc)::value;
+        float g[3], y[3], dp[3], xc[3], xi;
+        unsigned kk[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {      // real copies out of the ring (see k_tail3)
+            asm volatile("v_mov_b32 %0, %1" : "=v"(g[ch]) : "v"(gq[k][ch]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(y[ch]) : "v"(yq[k][ch]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(dp[ch]) : "v"(pq[k][ch]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(xc[ch]) : "v"(xq[k][ch]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(kk[ch]) : "v"(kq[k][ch]));
+        }
+        asm volatile("v_mov_b32 %0, %1" : "=v"(xi) : "v"(iq[k]));
+        issue(std::integral_constant<int, k>{}, i + PFD);
+        // dz of row i: (skip gradient + pooled gradient where this pixel was the window's first maximum) * act'(y)
+        const int pos = ((i & 1) << 1) | cpar;
+        float dz[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) dz[ch] = (g[ch] + ((int)kk[ch] == pos ? dp[ch] : 0.f)) * (y[ch] > 0.f ? 1.0f : yslope);
+        strip_expand<1>(dz, dzw[u % 3], la, ra);              // rows j-1 -> (u+1)%3, j -> (u+2)%3, j+1 -> u%3
+        iw[u % 3][0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(la, __builtin_bit_cast(int, xi)));
+        iw[u % 3][1] = xi;
+        iw[u % 3][2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ra, __builtin_bit_cast(int, xi)));
+        if constexpr (BWD) {
+            const int j = i - 1;
+            const float ownj = fmask(ownf, inside(j, r0, r1));
+            const float xv[3] = {xc[0] * ownj, xc[1] * ownj, xc[2] * ownj};
+            float dx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int wy = 0; wy < 3; ++wy)
+#pragma unroll
+                for (int wx = 0; wx < 3; ++wx)
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        const float d = dzw[(u + 1 + wy) % 3][wx * 3 + co];
+#pragma unroll
+                        for (int ci = 0; ci < 3; ++ci) {
+                            dx[ci] = fmaf(d, w[(((2 - wy) * 3 + (2 - wx)) * 3 + ci) * 3 + co], dx[ci]);
+                            acc[((wy * 3 + wx) * 3 + ci) * 3 + co] = fmaf(xv[ci], d, acc[((wy * 3 + wx) * 3 + ci) * 3 + co]);
+                        }
+                    }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) acc[81 + co] = fmaf(dzw[(u + 2) % 3][3 + co], ownj, acc[81 + co]);
+            // gradient of the first conv's pre-activation output at this pixel, and its weight / bias gradient from the input window
+            float d0[3];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) d0[ci] = dx[ci] * (xc[ci] > 0.f ? 1.0f : xslope) * ownj;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int co = 0; co < 3; ++co)
+                        acc0[(dy * 3 + kx) * 3 + co] = fmaf(iw[(u + 1 + dy) % 3][kx], d0[co], acc0[(dy * 3 + kx) * 3 + co]);
+#pragma unroll
+            for (int co = 0; co < 3; ++co) acc0[27 + co] += d0[co];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    const int nsteps = r1 - r0 + 2;
+    step(I0{}, No{}, r0 - 1);
+    step(I1{}, No{}, r0);                     // (its row j = r0 - 1 belongs to the chunk above)
+    step(I2{}, Yes{}, r0 + 1);
+    step(std::integral_constant<int, 3>{}, Yes{}, r0 + 2);
+    step(std::integral_constant<int, 4>{}, Yes{}, r0 + 3);
+    step(std::integral_constant<int, 5>{}, Yes{}, r0 + 4);
+#pragma unroll 1
+    for (int s0 = 6; s0 < nsteps; s0 += 6) {
+        step(I0{}, Yes{}, r0 - 1 + s0);
+        step(I1{}, Yes{}, r0 + s0);
+        step(I2{}, Yes{}, r0 + 1 + s0);
+        step(std::integral_constant<int, 3>{}, Yes{}, r0 + 2 + s0);
+        step(std::integral_constant<int, 4>{}, Yes{}, r0 + 3 + s0);
+        step(std::integral_constant<int, 5>{}, Yes{}, r0 + 4 + s0);
+    }
+    // ---- lane sums by DPP, the four waves through LDS, one atomic per element into the two slab sets (k_pg_fold layouts)
+#pragma unroll
+    for (int i = 0; i < NA1; ++i) {
+        const float s = wave_total_l63(acc[i]);
+        if (lane == 63) red[wave * NRED + i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < NA0; ++i) {
+        const float s = wave_total_l63(acc0[i]);
+        if (lane == 63) red[wave * NRED + NA1 + i] = s;
+    }
+    __syncthreads();
+    if (tid < NRED) {
+        const int e = tid;
+        const float v = (red[e] + red[NRED + e]) + (red[2 * NRED + e] + red[3 * NRED + e]);
+        if (e < NA1) {
+            int mrow, co;
+            if (e < 81) {
+                const int tap = e / 9, ci = (e / 3) % 3;
+                co = e % 3;
+                mrow = (2 - tap / 3) * 18 + (2 - tap % 3) * 3 + ci;
+            } else {
+                mrow = 3 * 18;
+                co = e - 81;
+            }
+            atomicAdd(p.slabs1 + (size_t)(blockIdx.x % NBK) * (4 * 256) + slab_index(mrow, co), v);
+        } else {
+            const int q = e - NA1;                        // (dy*3 + kx)*3 + co, or 27 + co
+            const int mrow = q < 27 ? (q / 9) * 6 + (q / 3) % 3 : 18, co = q % 3;
+            atomicAdd(p.slabs0 + (size_t)(blockIdx.x % NBK) * (2 * 256) + slab_index(mrow, co), v);
+        }
+    }
+}
+
 }  // namespace dnnca

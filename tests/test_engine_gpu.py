@@ -440,16 +440,18 @@ def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
     m.close()
 
 
-@pytest.mark.parametrize('B, H, W, tail', [(2, 40, 128, True), (8, 16, 256, True), (2, 40, 128, False), (8, 16, 256, False),
-                                           (3, 24, 200, True), (1, 72, 64, True)])
-def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypatch, B, H, W, tail):
+@pytest.mark.parametrize('B, H, W, strip', [(2, 40, 128, True), (8, 16, 256, True), (2, 40, 128, False), (8, 16, 256, False),
+                                            (3, 24, 200, True), (1, 72, 64, True)])
+def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypatch, B, H, W, strip):
     """configs/unet.yaml, the vector-ALU kernels of the full-resolution 3-channel level against the float64 oracle, every variable on
-    its own scale.  tail: the conv that feeds the head runs forward + head + loss + its whole backward in one column-strip launch
-    (k_tail3: strips of 60 columns, row chunks; shapes with partial strips, one strip, chunk counts not divisible by 8).  Without it
-    and on images made of whole 128 x 8 tiles that conv's backward is the tile kernel k_bwd3v (also behind the first encoder block,
-    with the folded max-pool backward); the (8, 16, 256) shape has a tile count divisible by 8 (the XCD-aware tile order)."""
-    if not tail:
+    its own scale.  strip: the column-strip kernels (strip_dev.h; strips of 60 columns, row chunks; shapes with partial strips, one
+    strip, chunk counts not divisible by 8) -- k_tail3: the conv that feeds the head runs forward + head + loss + its whole backward
+    in one launch; k_first3: the backward of the first encoder block (second conv with the folded max-pool backward + the first
+    conv's weight gradient) in one launch.  Without them and on images made of whole 128 x 8 tiles those convs' backward is the
+    tile kernel k_bwd3v (plain / with the pool fold); the (8, 16, 256) shape has a tile count divisible by 8 (XCD-aware order)."""
+    if not strip:
         monkeypatch.setenv('DNNCA_NO_TAIL3', '1')
+        monkeypatch.setenv('DNNCA_NO_FIRST3', '1')
     spec = O.ModelSpec('unet', 1, **UNET)
     params = Hp.perturbed_params(spec, np.float64)
     rng = np.random.default_rng(13)
@@ -467,9 +469,9 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
     floor = [10 * np.abs(g32[sl] - gref[sl]).max() for _, sl in Hp.tensor_slices(spec)]
     Hp.assert_grads_per_tensor(spec, m.get_grads(), gref, 2e-5, floor=floor)
     plan = set(r[0] for r in m.plan())
-    assert ('tail3_3x1_3' if tail else 'bwd3v_3x1_3') in plan, plan
-    if W % 128 == 0:
-        assert 'bwd3v_pool_3x1_3' in plan or not any(k.startswith('fz_down') for k in plan), plan
+    assert ('tail3_3x1_3' if strip else 'bwd3v_3x1_3') in plan, plan
+    if any(k.startswith('fz_down_1_3') for k in plan):        # the fused first block records the pool's window positions
+        assert ('first3_bwd' if strip else 'bwd3v_pool_3x1_3') in plan and 'pgbwd_w_1x1_3' not in plan or not strip, plan
     m.close()
 
 
