@@ -19,6 +19,8 @@ bool fast_conv_fwd_head(Model* m, int B, Op& o, Op& head, const float* y, const 
 bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* labels = nullptr);   // labels: also reduce them (first block only)
 // ... or, where the shape allows, that conv's forward, the head, the loss and the conv's whole backward in one launch (sets Model::tail_done)
 bool fast_tail3(Model* m, int B, Op& o, Op& head, const float* y, const dnnca_loss_cfg& cfg, float gscale);
+bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsigned char* pool_idx, const float* labels, float* label_part,
+                     double bytes, double flops, int* nblocks);      // first encoder block forward as one column-strip launch
 bool fast_head_in_conv_possible(Model* m);      // would fast_conv_fwd_head take the conv that feeds the head?
 bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);

@@ -639,6 +639,14 @@ bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* lab
     }
     const double bytes = 4.0 * B * H * W * (CIN + C1 + C1 + C1 + C1 + 0.25 * C1 + (labels ? 1 : 0));      // the three layers' algorithmic bytes
     const double flops = 2.0 * B * H * W * 9.0 * (CIN * C1 + C1 * C1);
+    if (CIN == 1 && C1 == 3) {          // the full-resolution block of configs/unet.yaml: the column-strip kernel (any even size)
+        int nblk = 0;
+        if (fast_first3_fwd(m, B, c1, c2, pl, a.y0, a.pool_idx, a.labels, a.label_part, bytes, flops, &nblk)) {
+            if (labels) { m->label_part_valid = true; m->label_part_nblk = nblk; }
+            pl.pool_idx_valid = store_mid && (m->dry || a.pool_idx != nullptr);
+            return true;
+        }
+    }
 #define X(cin, c1v, tw, th, nt, mw)                                                                                     \
     if (CIN == cin && C1 == c1v && W % tw == 0 && H % th == 0) {                                                  \
         a.tiles_x = W / tw; a.tiles_y = H / th;                                                                   \

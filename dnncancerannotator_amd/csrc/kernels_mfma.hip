@@ -620,6 +620,9 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         y0 = by * TH;
     };
     int tile = blockIdx.x;
+    int it = 0, buf = 0;
+    (void)it;          // read by the tuning build's stamps only
+    STAMP(6);
     if (tile < ntiles) {
         int b, x0, y0;
         decode(tile, b, x0, y0);
@@ -629,8 +632,6 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], b, x0, y0, p.B, p.H, p.W);
     }
 
-    int it = 0, buf = 0;
-    (void)it;          // read by the tuning build's stamps only
     if (DB && tile < ntiles) {
         tile_commit<CO, TW, NT>(preg, okg, lds4, tid);
 #pragma unroll
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         tile = next;
     }
 
+    STAMP_END(5);
     if constexpr (VW) {
         // lane sums by DPP, the block's four weight-gradient waves through LDS, then one atomic per element into slab
         // (blockIdx % NBUCKET).  The totals go where k_pg_fold expects D[(dy, j), (dx, co)]: everything in the dx = 0 entries
@@ -924,6 +926,7 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         const int s = i / (MT * 256), e = i - s * (MT * 256);
         atomicAdd(p.slabs[s] + (size_t)bucket * (MT * 256) + e, v);
     }
+    STAMP_END(7);
 }
 
 // ================================================================================================ B-operand prep
@@ -1859,6 +1862,34 @@ bool fast_conv_fwd_head(Model* m, int B, Op& o, Op& head, const float* y, const 
     // the partial sums wait for the launch that ends the backward pass (k_pg_fold)
     m->head_pending.partials = m->head_partials; m->head_pending.nblocks = g; m->head_pending.C = 3;
     m->head_pending.dw = m->g + head.w_off; m->head_pending.dbias = m->g + head.b_off;
+    return true;
+}
+
+// The forward pass of the first encoder block as one column-strip launch (k_first3_fwd, strip_dev.h); called by fused_down_fwd
+// (kernels_fused.hip), which owns the block's bookkeeping (pool positions, label partials).  nblocks: rows of the label table.
+bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsigned char* pool_idx, const float* labels, float* label_part,
+                     double bytes, double flops, int* nblocks) {
+    if (getenv("DNNCA_NO_FIRST3F") || c1.inA.d.C != 1 || c1.out.d.C != 3 || c2.out.d.C != 3) return false;
+    const int H = c1.out.d.H, W = c1.out.d.W;
+    if ((H & 1) || (W & 1) || W < 8 || H < 8 || (double)B * H * W * 12.0 >= 1073741824.0 || c1.alpha > 1.f || c2.alpha > 1.f) return false;
+    FirstFwdArgs a{};
+    a.xin = c1.inA.d.p;
+    a.w0 = m->p + c1.w_off; a.b0 = m->p + c1.b_off;
+    a.w1 = m->p + c2.w_off; a.b1 = m->p + c2.b_off;
+    a.alpha0 = c1.alpha; a.alpha1 = c2.alpha;
+    a.y0 = y0; a.y1 = c2.out.d.p;
+    a.pool = pool.out.d.p; a.pool_idx = pool_idx;
+    a.labels = labels; a.label_part = label_part;
+    a.B = B; a.H = H; a.W = W;
+    a.nstrips = (W + STRIP - 1) / STRIP;
+    int nchunks = 2048 / (B * a.nstrips);
+    if (nchunks > H / 8) nchunks = H / 8;
+    if (nchunks < 1) nchunks = 1;
+    a.nchunks = nchunks;
+    const int nblk = (B * nchunks * a.nstrips + 3) / 4;
+    if (nblk > 2048) return false;
+    LAUNCH(m, "first3_fwd", bytes, flops, hipLaunchKernelGGL((k_first3_fwd<0, 27>), dim3(nblk), dim3(256), 0, m->stream, a));
+    *nblocks = nblk;
     return true;
 }
 

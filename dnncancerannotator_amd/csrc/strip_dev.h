@@ -598,4 +598,229 @@ __global__ __launch_bounds__(256, 2) void k_first3(FirstArgs p) {
     }
 }
 
+// k_first3_fwd: the forward pass of the first encoder block (components.py:46-61,77-81: conv 1 -> 3, conv 3 -> 3, 2x2 max-pool) in one
+// column-strip pass, with the label statistics of a train step (utils/losses.py:87-102) riding along: reads the network input (and
+// the labels), writes the two conv outputs, the pooled tensor and the window position of every pooled maximum.  Chunks start on even
+// rows, and strips on even columns, so that a 2x2 pooling window never straddles two waves: its two rows are consecutive steps of one
+// lane pair (the partner's values come through a quad-permute DPP).
+struct FirstFwdArgs {
+    const float* xin;        // network input [B, H, W, 1]
+    const float* w0;         // first conv: kernel HWIO [3][3][1][3] and bias
+    const float* b0;
+    const float* w1;         // second conv: kernel HWIO (81) and bias
+    const float* b1;
+    float alpha0, alpha1;    // activation slopes (< 0: none)
+    float* y0;               // first conv's output [B, H, W, 3] or nullptr (no backward pass follows)
+    float* y1;               // second conv's output
+    float* pool;             // [B, H/2, W/2, 3]
+    unsigned char* pool_idx; // [B, H/2, W/2, 3] window position (0..3, row-major) of each pooled value's FIRST maximum, or nullptr
+    const float* labels;     // [B, H, W] or nullptr
+    float* label_part;       // [gridDim.x][4] per-block (sum, min, max, -)
+    int B, H, W;
+    int nstrips, nchunks;
+};
+
+template <int WS0, int WS1>      // how many of the 27 / 81 kernel weights are scalar-register operands (the rest: vector registers)
+__global__ __launch_bounds__(256, 2) void k_first3_fwd(FirstFwdArgs p) {
+    constexpr int PFD = 6;           // rows in flight per lane (8 bytes each: the steps are short, three rows ahead did not cover the latency)
+    __shared__ float red[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ntasks = p.B * p.nchunks * p.nstrips;
+    const int t0 = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
+    const int t = t0 < ntasks ? t0 : ntasks - 1;
+    const int strip = t % p.nstrips, ck = (t / p.nstrips) % p.nchunks, b = t / (p.nstrips * p.nchunks);
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    const int r0 = 2 * (int)((long long)ck * Hp / p.nchunks), r1 = 2 * (int)((long long)(ck + 1) * Hp / p.nchunks);     // even rows
+    const int c = strip * STRIP - 2 + lane;
+    const bool col_ok = (unsigned)c < (unsigned)p.W;
+    const bool lane_own = lane >= 2 && lane < 2 + STRIP && col_ok && t0 < ntasks;
+    const unsigned npix = (unsigned)p.B * p.H * p.W, npool = (unsigned)p.B * Hp * Wp;
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)p.xin, 0, npix * 4u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)p.labels, 0, p.labels ? npix * 4u : 0u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.y0, 0, p.y0 ? npix * 12u : 0u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.y1, 0, npix * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void*)p.pool, 0, npool * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)p.pool_idx, 0, p.pool_idx ? npool * 3u : 0u, STRIP_RSRC);
+    unsigned col4 = col_ok ? (unsigned)c * 4u : STRIP_HALF, own12 = lane_own ? (unsigned)c * 12u : STRIP_HALF;
+    // pooled tensor: the even lane of a pair stores the window's maximum
+    const bool pool_lane = lane_own && !(lane & 1);
+    unsigned ownp12 = pool_lane ? (unsigned)(c >> 1) * 12u : STRIP_HALF, ownp3 = pool_lane ? (unsigned)(c >> 1) * 3u : STRIP_HALF;
+    float colf = col_ok ? 1.0f : 0.f, ownf = lane_own ? 1.0f : 0.f;
+    int la = ((lane + 63) & 63) * 4, ra = ((lane + 1) & 63) * 4;
+    asm volatile("" : "+v"(col4), "+v"(own12), "+v"(ownp12), "+v"(ownp3), "+v"(colf), "+v"(ownf), "+v"(la), "+v"(ra));
+    const unsigned img0 = (unsigned)b * p.H, imgp0 = (unsigned)b * Hp;
+    auto inside = [](int row, int lo, int hi) -> unsigned { return ~(unsigned)(((row - lo) | (hi - 1 - row)) >> 31); };
+    auto rowpart = [&](unsigned row0, int row, unsigned ok, unsigned rowbytes) -> unsigned {   // uniform
+        return ((row0 + (unsigned)row) * rowbytes & ok) | (STRIP_HALF & ~ok);
+    };
+    auto fmask = [](float v, unsigned m) -> float { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m); };
+
+    unsigned xq[PFD], lq[PFD];       // ring: network-input row i and label row i of the step that consumes the slot
+    auto issue = [&](auto kc, int i) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned off = col4 + rowpart(img0, i, inside(i, 0, p.H), (unsigned)p.W * 4u);
+        xq[k] = __builtin_amdgcn_raw_buffer_load_b32(rsi, off, 0, 0);
+        lq[k] = __builtin_amdgcn_raw_buffer_load_b32(rsl, off, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+    issue(I0{}, r0 - 2);
+    issue(I1{}, r0 - 1);
+    issue(I2{}, r0);
+    issue(I3{}, r0 + 1);
+    issue(I4{}, r0 + 2);
+    issue(I5{}, r0 + 3);
+    float w0[27], w1[81];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) w0[i] = p.w0[i];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) w1[i] = p.w1[i];
+    float b0[3] = {p.b0[0], p.b0[1], p.b0[2]}, b1[3] = {p.b1[0], p.b1[1], p.b1[2]};
+    float a0 = p.alpha0 < 0.f ? 1.0f : p.alpha0, a1 = p.alpha1 < 0.f ? 1.0f : p.alpha1;
+    __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0) lgkmcnt(0): nothing pending at the loop's entry (see k_tail3)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) asm volatile("" : "+v"(b0[cc]), "+v"(b1[cc]));
+    asm volatile("" : "+v"(a0), "+v"(a1));
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+        if (i < WS0) w0[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w0[i])));
+        else asm volatile("" : "+v"(w0[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 81; ++i) {
+        if (i < WS1) w1[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w1[i])));
+        else asm volatile("" : "+v"(w1[i]));
+    }
+    float iw[3][3], yw[3][9], prev[3] = {0.f, 0.f, 0.f};
+    float lsum = 0.f, lmin = INFINITY, lmax = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) iw[s][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) yw[s][i] = 0.f;
+    }
+    // step s (u = s mod 6; window slot u mod 3): input row i = r0 - 2 + s arrives; C0: first conv of row i - 1; C1: second conv of row i - 2 (+ pool)
+    auto step = [&](auto uc, auto c0c, auto c1c, int i) {
+        constexpr int uu = decltype(uc)::value, u = uu % 3;
+        constexpr bool C0 = decltype(c0c)::value, C1 = decltype(c1c)::value;
+        float xi, lab;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(xi) : "v"(xq[uu]));      // real copies out of the ring (see k_tail3)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lab) : "v"(lq[uu]));
+        issue(std::integral_constant<int, uu>{}, i + PFD);
+        iw[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(la, __builtin_bit_cast(int, xi)));
+        iw[u][1] = xi;
+        iw[u][2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ra, __builtin_bit_cast(int, xi)));
+        if (p.labels) {                // uniform; a pixel's label is counted by the wave that owns the pixel
+            const unsigned mine = inside(i, r0, r1);
+            const float lo = fmask(ownf, mine);
+            lsum = fmaf(lab, lo, lsum);
+            lmin = fminf(lmin, lo > 0.f ? lab : INFINITY);
+            lmax = fmaxf(lmax, lo > 0.f ? lab : -INFINITY);
+        }
+        if constexpr (C0) {
+            // ---- first conv of row i - 1 (input rows i-2 .. i = window slots (u+1)%3, (u+2)%3, u); zero outside the image (it is
+            // the second conv's zero padding there)
+            const int rf = i - 1;
+            float f[3] = {b0[0], b0[1], b0[2]};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) f[co] = fmaf(iw[(u + 1 + dy) % 3][kx], w0[(dy * 3 + kx) * 3 + co], f[co]);
+            const float imgf = fmask(colf, inside(rf, 0, p.H));
+#pragma unroll
+            for (int co = 0; co < 3; ++co) f[co] = fmaxf(f[co], f[co] * a0) * imgf;
+            const unsigned mine = inside(rf, r0, r1);
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b96(rs0, 0, 0, 0)), f3{f[0], f[1], f[2]}),
+                                                  rs0, own12 + rowpart(img0, rf, mine, (unsigned)p.W * 12u), 0, 0);
+            strip_expand<1>(f, yw[u], la, ra);            // y0 window slots: row i-3 -> (u+1)%3, i-2 -> (u+2)%3, i-1 -> u
+        }
+        if constexpr (C1) {
+            // ---- second conv of row j = i - 2 (y0 rows i-3 .. i-1), activation, store; 2x2 max-pool over the row pair (j - 1, j)
+            const int j = i - 2;
+            float g[3] = {b1[0], b1[1], b1[2]}, g2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float xv = yw[(u + 1 + dy) % 3][k];
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        if ((dy * 9 + k) & 1) g2[co] = fmaf(xv, w1[(dy * 9 + k) * 3 + co], g2[co]);
+                        else g[co] = fmaf(xv, w1[(dy * 9 + k) * 3 + co], g[co]);
+                    }
+                }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                g[co] += g2[co];
+                g[co] = fmaxf(g[co], g[co] * a1);
+            }
+            const unsigned mine = inside(j, r0, r1);
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b96(rs1, 0, 0, 0)), f3{g[0], g[1], g[2]}),
+                                                  rs1, own12 + rowpart(img0, j, mine, (unsigned)p.W * 12u), 0, 0);
+            // pool: on odd rows the window (rows j-1, j; this lane's column and its pair partner's) is complete.  First maximum in
+            // row-major order: (j-1, even) = 0, (j-1, odd) = 1, (j, even) = 2, (j, odd) = 3.  (On even rows the values are computed and
+            // dropped: the store offset is out of range.)
+            float pm[3];
+            unsigned pos[3];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                const float p01 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, prev[co]), 0xB1, 0xf, 0xf, false));
+                const float p11 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, g[co]), 0xB1, 0xf, 0xf, false));
+                const float m = fmaxf(fmaxf(prev[co], p01), fmaxf(g[co], p11));
+                pm[co] = m;
+                pos[co] = prev[co] == m ? 0u : (p01 == m ? 1u : (g[co] == m ? 2u : 3u));
+                prev[co] = g[co];
+            }
+            const unsigned podd = mine & (unsigned)-(j & 1);          // an odd row of this chunk
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b96(rsp, 0, 0, 0)), f3{pm[0], pm[1], pm[2]}),
+                                                  rsp, ownp12 + rowpart(imgp0, j >> 1, podd, (unsigned)Wp * 12u), 0, 0);
+            const unsigned o3 = ownp3 + rowpart(imgp0, j >> 1, podd, (unsigned)Wp * 3u);
+#pragma unroll
+            for (int co = 0; co < 3; ++co) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)pos[co], rsk, o3 + co, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    const int nsteps = r1 - r0 + 4;
+    step(I0{}, No{}, No{}, r0 - 2);
+    step(I1{}, No{}, No{}, r0 - 1);
+    step(I2{}, Yes{}, No{}, r0);
+    step(I3{}, Yes{}, No{}, r0 + 1);
+    step(I4{}, Yes{}, Yes{}, r0 + 2);
+    step(I5{}, Yes{}, Yes{}, r0 + 3);
+#pragma unroll 1
+    for (int s0 = 6; s0 < nsteps; s0 += 6) {
+        step(I0{}, Yes{}, Yes{}, r0 - 2 + s0);
+        step(I1{}, Yes{}, Yes{}, r0 - 1 + s0);
+        step(I2{}, Yes{}, Yes{}, r0 + s0);
+        step(I3{}, Yes{}, Yes{}, r0 + 1 + s0);
+        step(I4{}, Yes{}, Yes{}, r0 + 2 + s0);
+        step(I5{}, Yes{}, Yes{}, r0 + 3 + s0);
+    }
+    if (p.labels) {           // block partials of the label statistics: wave shuffles, the waves through LDS, one table row
+        for (int o = 32; o > 0; o >>= 1) {
+            lsum += __shfl_down(lsum, o, 64);
+            lmin = fminf(lmin, __shfl_down(lmin, o, 64));
+            lmax = fmaxf(lmax, __shfl_down(lmax, o, 64));
+        }
+        if (lane == 0) { red[wave] = lsum; red[4 + wave] = lmin; red[8 + wave] = lmax; }
+        __syncthreads();
+        if (tid == 0)
+            reinterpret_cast<float4*>(p.label_part)[blockIdx.x] =
+                make_float4((red[0] + red[1]) + (red[2] + red[3]), fminf(fminf(red[4], red[5]), fminf(red[6], red[7])),
+                            fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])), 0.f);
+    }
+}
+
 }  // namespace dnnca

@@ -146,7 +146,7 @@ def test_full_size_label_statistics_ride_in_the_first_block(gpu):
     m = gpu.DeviceModel('unet', 1, H, W, B, **UNET)
     m.init_glorot(seed=2)
     names = [r[0] for r in m.plan()]
-    assert 'tail3_3x1_3' in names and 'fz_down_1_3' in names and 'label_stats4' not in names and 'head_train_3' not in names
+    assert 'tail3_3x1_3' in names and 'first3_fwd' in names and 'label_stats4' not in names and 'head_train_3' not in names
     cfg = m.loss_cfg(weight_mul=3.0, weight_add=0.25)
     out = m.train_step(x, y, 0.0, cfg)
     pr = float(y.astype(np.float64).mean())
@@ -470,7 +470,7 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
     Hp.assert_grads_per_tensor(spec, m.get_grads(), gref, 2e-5, floor=floor)
     plan = set(r[0] for r in m.plan())
     assert ('tail3_3x1_3' if strip else 'bwd3v_3x1_3') in plan, plan
-    if any(k.startswith('fz_down_1_3') for k in plan):        # the fused first block records the pool's window positions
+    if 'fz_down_1_3' in plan or 'first3_fwd' in plan:          # the fused first block records the pool's window positions
         assert ('first3_bwd' if strip else 'bwd3v_pool_3x1_3') in plan and 'pgbwd_w_1x1_3' not in plan or not strip, plan
     m.close()
 
