@@ -1693,7 +1693,9 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
             f.nchunks = nchunks;
             const int nblk = (B * nchunks * f.nstrips + 3) / 4;
             const double npx = (double)B * a.H * a.W;
-            LAUNCH(m, "first3_bwd", 4.0 * npx * (3 + 3 + 3 + 1 + 0.75) + 0.75 * npx, 2.0 * npx * (162 + 30),
+            // algorithmic bytes of the layers this launch stands for: pool backward (y, dy in; dx in/out; pooled gradient) 3 + 3 + 0.75 + 0.75,
+            // second conv backward 3 + 3 + 3, first conv weight gradient 3 + 1 floats per pixel
+            LAUNCH(m, "first3_bwd", 4.0 * npx * 20.5, 2.0 * npx * (162 + 30),
                    hipLaunchKernelGGL((k_first3<2, 40>), dim3(nblk), dim3(256), 0, m->stream, f));
             m->first_done = c0;
             return true;
@@ -1879,16 +1881,25 @@ bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsig
     a.alpha0 = c1.alpha; a.alpha1 = c2.alpha;
     a.y0 = y0; a.y1 = c2.out.d.p;
     a.pool = pool.out.d.p; a.pool_idx = pool_idx;
+    if (const char* e = getenv("DNNCA_F3F_ABL")) {      // tuning aid (wrong results): drop output tensors
+        const int abl = atoi(e);
+        if (abl & 1) a.y0 = nullptr;
+        if (abl & 2) a.pool_idx = nullptr;
+    }
     a.labels = labels; a.label_part = label_part;
     a.B = B; a.H = H; a.W = W;
     a.nstrips = (W + STRIP - 1) / STRIP;
-    int nchunks = 2048 / (B * a.nstrips);
+    static const int wps = getenv("DNNCA_F3F_WPS") ? atoi(getenv("DNNCA_F3F_WPS")) : 2;      // tuning aid: waves per SIMD
+    int nchunks = 1024 * wps / (B * a.nstrips);
     if (nchunks > H / 8) nchunks = H / 8;
     if (nchunks < 1) nchunks = 1;
     a.nchunks = nchunks;
     const int nblk = (B * nchunks * a.nstrips + 3) / 4;
     if (nblk > 2048) return false;
-    LAUNCH(m, "first3_fwd", bytes, flops, hipLaunchKernelGGL((k_first3_fwd<0, 27>), dim3(nblk), dim3(256), 0, m->stream, a));
+    if (wps == 3)
+        LAUNCH(m, "first3_fwd", bytes, flops, hipLaunchKernelGGL((k_first3_fwd<0, 27, 3>), dim3(nblk), dim3(256), 0, m->stream, a));
+    else
+        LAUNCH(m, "first3_fwd", bytes, flops, hipLaunchKernelGGL((k_first3_fwd<0, 27>), dim3(nblk), dim3(256), 0, m->stream, a));
     *nblocks = nblk;
     return true;
 }
@@ -1953,7 +1964,9 @@ bool fast_tail3(Model* m, int B, Op& o, Op& head, const float* y, const dnnca_lo
              : abl == 16 ? k_tail3<3, 27, true, 16> : abl == 7 ? k_tail3<3, 27, true, 7> : k_tail3<3, 27, true, 31>;
     }
 #endif
-    LAUNCH(m, "tail3_3x1_3", 4.0 * npx * (3 + 1 + 3), 2.0 * npx * (81 * 3 + 4),
+    // algorithmic bytes / FLOPs of the layers this launch stands for (every layer reads its inputs and writes its output):
+    // conv forward 3 + 3, head + loss + head backward 3 + 1 + 3, conv backward (dz, x in; dx out) 3 + 3 + 3 floats per pixel
+    LAUNCH(m, "tail3_3x1_3", 4.0 * npx * 22, 2.0 * npx * (81 * 3 + 15),
            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), tail3_lds, m->stream, a));
     m->head_pending.partials = m->head_partials; m->head_pending.nblocks = nblk; m->head_pending.C = 3;
     m->head_pending.dw = m->g + head.w_off; m->head_pending.dbias = m->g + head.b_off;

@@ -620,8 +620,8 @@ struct FirstFwdArgs {
     int nstrips, nchunks;
 };
 
-template <int WS0, int WS1>      // how many of the 27 / 81 kernel weights are scalar-register operands (the rest: vector registers)
-__global__ __launch_bounds__(256, 2) void k_first3_fwd(FirstFwdArgs p) {
+template <int WS0, int WS1, int WPS = 2>      // how many of the 27 / 81 kernel weights are scalar-register operands (the rest: vector registers); waves per SIMD
+__global__ __launch_bounds__(256, WPS) void k_first3_fwd(FirstFwdArgs p) {
     constexpr int PFD = 6;           // rows in flight per lane (8 bytes each: the steps are short, three rows ahead did not cover the latency)
     __shared__ float red[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void k_first3_fwd(FirstFwdArgs p) {
 #pragma unroll
             for (int co = 0; co < 3; ++co) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)pos[co], rsk, o3 + co, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WPS == 2) __builtin_amdgcn_sched_barrier(0);
     };
     using Yes = std::true_type;
     using No = std::false_type;
