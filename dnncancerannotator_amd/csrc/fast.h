@@ -21,6 +21,7 @@ bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* lab
 bool fast_tail3(Model* m, int B, Op& o, Op& head, const float* y, const dnnca_loss_cfg& cfg, float gscale);
 bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsigned char* pool_idx, const float* labels, float* label_part,
                      double bytes, double flops, int* nblocks);      // first encoder block forward as one column-strip launch
+bool fast_up3_fwd(Model* m, int B, size_t oi);     // last decoder block: transposed conv + two-source conv forward in one column-strip launch
 bool fast_head_in_conv_possible(Model* m);      // would fast_conv_fwd_head take the conv that feeds the head?
 bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);

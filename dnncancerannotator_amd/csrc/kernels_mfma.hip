@@ -1904,6 +1904,38 @@ bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsig
     return true;
 }
 
+// Conv2DTranspose 6 -> 3 followed by the two-source conv 6 -> 3 of the last decoder block (forward) as one column-strip launch
+// (k_up3_fwd, strip_dev.h); ops[oi], ops[oi + 1] are consumed when it returns true.
+bool fast_up3_fwd(Model* m, int B, size_t oi) {
+    if (getenv("DNNCA_NO_UP3F") || (m->desc.flags & 1) || oi + 1 >= m->ops.size()) return false;
+    Op &tc = m->ops[oi], &c0 = m->ops[oi + 1];
+    if (tc.type != OP_TCONV || c0.type != OP_CONV || tc.k != 2 || c0.k != 3) return false;
+    if (tc.inA.d.C != 6 || tc.out.d.C != 3 || c0.inA.d.C != 3 || c0.inB.d.C != 3 || c0.out.d.C != 3) return false;
+    if (c0.inA.d.p != tc.out.d.p || !dense(tc.inA.d) || !dense(tc.out.d) || !dense(c0.inB.d) || !dense(c0.out.d)) return false;
+    if (!conv_supported(m, c0) || !fast_tconv_supported(m, tc)) return false;
+    const int H = c0.out.d.H, W = c0.out.d.W;
+    if (tc.out.d.H != H || tc.out.d.W != W || c0.inB.d.H != H || c0.inB.d.W != W || tc.inA.d.H * 2 != H || tc.inA.d.W * 2 != W) return false;
+    if ((H & 1) || (W & 1) || W < 8 || H < 8 || (double)B * H * W * 12.0 >= 1073741824.0 || c0.alpha > 1.f) return false;
+    UpFwdArgs a{};
+    a.in = tc.inA.d.p; a.skip = c0.inB.d.p;
+    a.wt = m->p + tc.w_off; a.bt = m->p + tc.b_off;
+    a.w = m->p + c0.w_off; a.b = m->p + c0.b_off;
+    a.alpha = c0.alpha;
+    a.tout = tc.out.d.p; a.out = c0.out.d.p;
+    a.B = B; a.H = H; a.W = W;
+    a.nstrips = (W + STRIP - 1) / STRIP;
+    int nchunks = 2048 / (B * a.nstrips);
+    if (nchunks > H / 8) nchunks = H / 8;
+    if (nchunks < 1) nchunks = 1;
+    a.nchunks = nchunks;
+    const int nblk = (B * nchunks * a.nstrips + 3) / 4;
+    const double npx = (double)B * H * W;
+    // algorithmic bytes of the two layers: transposed conv (1.5 in, 3 out), conv (3 + 3 in, 3 out) floats per pixel
+    LAUNCH(m, "up3_fwd", 4.0 * npx * 13.5, 2.0 * npx * (18 + 162),
+           hipLaunchKernelGGL((k_up3_fwd<2, 48>), dim3(nblk), dim3(256), 0, m->stream, a));
+    return true;
+}
+
 // The conv that feeds the head in a training step, whole: forward + head + weighted BCE + head backward + the conv's own backward
 // in one column-strip launch (k_tail3, strip_dev.h).  The conv's output and its gradient are never written; the caller skips the
 // conv's backward launch (Model::tail_done).  Returns false when the shape has no such kernel.

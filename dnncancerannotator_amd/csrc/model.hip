@@ -487,6 +487,10 @@ int Model::forward(const float* x_dev, int B, bool training) {
                     oi += 2;
                     break;
                 }
+                if (!generic && fast_up3_fwd(this, B, oi)) {                  // tconv + two-source conv of the 3-channel level
+                    oi += 1;
+                    break;
+                }
                 Op* bn_next = (training && oi + 1 < ops.size() && ops[oi + 1].type == OP_BN && ops[oi + 1].inA.d.p == o.out.d.p &&
                                fast_bn_supported(this, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
                 if (!generic && (fast_tconv_fwd(this, B, o, bytes, flops) || ig_tconv_fwd(this, B, o, bytes, flops, bn_next))) break;

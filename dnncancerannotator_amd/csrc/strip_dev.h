@@ -823,4 +823,171 @@ __global__ __launch_bounds__(256, WPS) void k_first3_fwd(FirstFwdArgs p) {
     }
 }
 
+// k_up3_fwd: the first two layers of the last decoder block's forward pass (components.py:118-127,158-166: Conv2DTranspose 6 -> 3,
+// 2x2 stride 2; concat [up, skip]; conv 6 -> 3) in one column-strip pass: a lane computes the transposed conv's output pixel itself
+// (one input pixel of the half-resolution tensor, the kernel slice of its row / column parity), writes it (the backward pass reads it)
+// and feeds it, beside the skip tensor's pixel, into the two three-row windows of the 3x3 conv.  Chunks start on even rows and strips
+// on even columns, so a row's parity is the step's parity (compile time) and a lane's column parity is its lane parity.
+struct UpFwdArgs {
+    const float* in;         // half-resolution input [B, H/2, W/2, 6]
+    const float* skip;       // skip tensor [B, H, W, 3]
+    const float* wt;         // transposed conv: kernel [2][2][3][6] (a, e, co, ci) and bias (3)
+    const float* bt;
+    const float* w;          // conv: kernel HWIO [3][3][6][3] (input channels: 3 up, 3 skip) and bias
+    const float* b;
+    float alpha;             // the conv's activation slope (< 0: none)
+    float* tout;             // transposed conv's output [B, H, W, 3]
+    float* out;              // conv's output [B, H, W, 3]
+    int B, H, W;
+    int nstrips, nchunks;
+};
+
+template <int PFD, int WS>      // WS of the conv's 162 weights are scalar-register operands, the rest sit in vector registers
+__global__ __launch_bounds__(256, 2) void k_up3_fwd(UpFwdArgs p) {
+    static_assert(PFD == 2 || PFD == 3, "ring slots; the row loop is unrolled 6 times");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ntasks = p.B * p.nchunks * p.nstrips;
+    const int t0 = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
+    const int t = t0 < ntasks ? t0 : ntasks - 1;
+    const int strip = t % p.nstrips, ck = (t / p.nstrips) % p.nchunks, b = t / (p.nstrips * p.nchunks);
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    const int r0 = 2 * (int)((long long)ck * Hp / p.nchunks), r1 = 2 * (int)((long long)(ck + 1) * Hp / p.nchunks);     // even rows
+    const int c = strip * STRIP - 2 + lane;
+    const bool col_ok = (unsigned)c < (unsigned)p.W;
+    const bool lane_own = lane >= 2 && lane < 2 + STRIP && col_ok && t0 < ntasks;
+    const unsigned npix = (unsigned)p.B * p.H * p.W, npool = (unsigned)p.B * Hp * Wp;
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, npool * 24u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)p.skip, 0, npix * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)p.tout, 0, npix * 12u, STRIP_RSRC);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, npix * 12u, STRIP_RSRC);
+    unsigned col12 = col_ok ? (unsigned)c * 12u : STRIP_HALF, colp24 = col_ok ? (unsigned)(c >> 1) * 24u : STRIP_HALF;
+    unsigned own12 = lane_own ? (unsigned)c * 12u : STRIP_HALF;
+    float colf = col_ok ? 1.0f : 0.f;
+    int la = ((lane + 63) & 63) * 4, ra = ((lane + 1) & 63) * 4;
+    asm volatile("" : "+v"(col12), "+v"(colp24), "+v"(own12), "+v"(colf), "+v"(la), "+v"(ra));
+    const unsigned img0 = (unsigned)b * p.H, imgp0 = (unsigned)b * Hp;
+    auto inside = [](int row, int lo, int hi) -> unsigned { return ~(unsigned)(((row - lo) | (hi - 1 - row)) >> 31); };
+    auto rowpart = [&](unsigned row0, int row, unsigned ok, unsigned rowbytes) -> unsigned {   // uniform
+        return ((row0 + (unsigned)row) * rowbytes & ok) | (STRIP_HALF & ~ok);
+    };
+    auto fmask = [](float v, unsigned m) -> float { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m); };
+
+    f3 sq[PFD], iq0[PFD], iq1[PFD];      // ring: skip row i, half-resolution input row i/2 (6 channels) of the step that consumes the slot
+    auto issue = [&](auto kc, int i) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned ok = inside(i, 0, p.H);
+        sq[k] = strip_load3(rss, col12 + rowpart(img0, i, ok, (unsigned)p.W * 12u));
+        const unsigned o = colp24 + rowpart(imgp0, i >> 1, ok, (unsigned)Wp * 24u);
+        iq0[k] = strip_load3(rsi, o);
+        iq1[k] = strip_load3(rsi, o + 12u);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    issue(I0{}, r0 - 1);
+    issue(I1{}, r0);
+    if constexpr (PFD == 3) issue(I2{}, r0 + 1);
+    // transposed-conv kernel slices of this lane's column parity e: wt[a][co][ci] = Wt[a][e][co][ci]
+    float wt[2][3][6], bt[3], bc[3], w[162];
+    const int e = c & 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int co = 0; co < 3; ++co)
+#pragma unroll
+            for (int ci = 0; ci < 6; ++ci) wt[a][co][ci] = p.wt[((a * 2 + e) * 3 + co) * 6 + ci];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) { bt[co] = p.bt[co]; bc[co] = p.b[co]; }
+#pragma unroll
+    for (int i = 0; i < 162; ++i) w[i] = p.w[i];
+    float aslope = p.alpha < 0.f ? 1.0f : p.alpha;
+    __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0) lgkmcnt(0): nothing pending at the loop's entry (see k_tail3)
+#pragma unroll
+    for (int co = 0; co < 3; ++co) asm volatile("" : "+v"(bt[co]), "+v"(bc[co]));
+    asm volatile("" : "+v"(aslope));
+#pragma unroll
+    for (int i = 0; i < 162; ++i) {
+        if (i < WS) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[i])));
+        else asm volatile("" : "+v"(w[i]));
+    }
+    float ta[3][9], sk[3][9];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { ta[s][i] = 0.f; sk[s][i] = 0.f; }
+    // step s (uu = s mod 6; window slot u = uu mod 3): rows i = r0 - 1 + s arrive -> transposed conv of row i (row parity a = (uu + 1) & 1),
+    // both rows into the windows; CONV: the 3x3 conv of row j = i - 1
+    auto step = [&](auto uc, auto convc, int i) {
+        constexpr int uu = decltype(uc)::value, u = uu % 3, k = uu % PFD, a = (uu + 1) & 1;
+        constexpr bool CONV = decltype(convc)::value;
+        float s3[3], x6[6];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {      // real copies out of the ring (see k_tail3)
+            asm volatile("v_mov_b32 %0, %1" : "=v"(s3[ch]) : "v"(sq[k][ch]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(x6[ch]) : "v"(iq0[k][ch]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(x6[3 + ch]) : "v"(iq1[k][ch]));
+        }
+        issue(std::integral_constant<int, k>{}, i + PFD);
+        // transposed conv at (i, c); zero outside the image (the conv's zero padding)
+        const float imgf = fmask(colf, inside(i, 0, p.H));
+        float tv[3];
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            float acc = bt[co];
+#pragma unroll
+            for (int ci = 0; ci < 6; ++ci) acc = fmaf(x6[ci], wt[a][co][ci], acc);
+            tv[co] = acc * imgf;
+        }
+        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b96(rst, 0, 0, 0)), f3{tv[0], tv[1], tv[2]}),
+                                              rst, own12 + rowpart(img0, i, inside(i, r0, r1), (unsigned)p.W * 12u), 0, 0);
+        strip_expand<1>(tv, ta[u], la, ra);             // rows j-1 -> (u+1)%3, j -> (u+2)%3, j+1 -> u
+        strip_expand<1>(s3, sk[u], la, ra);
+        if constexpr (CONV) {
+            const int j = i - 1;
+            float g[3] = {bc[0], bc[1], bc[2]}, g2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int kk = 0; kk < 9; ++kk) {
+                    const int kx = kk / 3, ci = kk % 3;
+                    const float xa = ta[(u + 1 + dy) % 3][kk], xb = sk[(u + 1 + dy) % 3][kk];
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        g[co] = fmaf(xa, w[((dy * 3 + kx) * 6 + ci) * 3 + co], g[co]);
+                        g2[co] = fmaf(xb, w[((dy * 3 + kx) * 6 + 3 + ci) * 3 + co], g2[co]);
+                    }
+                }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                g[co] += g2[co];
+                g[co] = fmaxf(g[co], g[co] * aslope);
+            }
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b96(rso, 0, 0, 0)), f3{g[0], g[1], g[2]}),
+                                                  rso, own12 + rowpart(img0, j, inside(j, r0, r1), (unsigned)p.W * 12u), 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    const int nsteps = r1 - r0 + 2;
+    step(I0{}, No{}, r0 - 1);
+    step(I1{}, No{}, r0);                     // (its row j = r0 - 1 belongs to the chunk above)
+    step(I2{}, Yes{}, r0 + 1);
+    step(std::integral_constant<int, 3>{}, Yes{}, r0 + 2);
+    step(std::integral_constant<int, 4>{}, Yes{}, r0 + 3);
+    step(std::integral_constant<int, 5>{}, Yes{}, r0 + 4);
+#pragma unroll 1
+    for (int s0 = 6; s0 < nsteps; s0 += 6) {
+        step(I0{}, Yes{}, r0 - 1 + s0);
+        step(I1{}, Yes{}, r0 + s0);
+        step(I2{}, Yes{}, r0 + 1 + s0);
+        step(std::integral_constant<int, 3>{}, Yes{}, r0 + 2 + s0);
+        step(std::integral_constant<int, 4>{}, Yes{}, r0 + 3 + s0);
+        step(std::integral_constant<int, 5>{}, Yes{}, r0 + 4 + s0);
+    }
+}
+
 }  // namespace dnnca

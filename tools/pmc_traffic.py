@@ -32,6 +32,12 @@ def short_name(k):
     m = re.match(r'dnnca::fz::k_fz_(down|up)<(\d+), (\d+)', k)
     if m:
         return 'fz_%s_%s_%s' % m.groups()
+    m = re.match(r'dnnca::k_bwd3v<(true|false)', k)
+    if m:
+        return 'bwd3v_pool_3x1_3' if m.group(1) == 'true' else 'bwd3v_3x1_3'
+    for kern, name in (('k_tail3<', 'tail3_3x1_3'), ('k_first3_fwd<', 'first3_fwd'), ('k_first3<', 'first3_bwd')):
+        if k.startswith('dnnca::' + kern):
+            return name
     m = re.match(r'dnnca::(?:ig::|igb::|first::)?k_(\w+)', k)
     if m:
         return m.group(1)
