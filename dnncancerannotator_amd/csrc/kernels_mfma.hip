@@ -143,14 +143,18 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
     // B operand (one register per K-step) and bias first; drain them and hide their origin from the compiler:
     // otherwise hipcc keeps `s_waitcnt vmcnt(..0)` for these registers inside the tile loop, and since vmcnt retires in
     // order that wait also drains the tile prefetch issued just before the MFMAs (load latency serialised per tile).
+    // (the drain sits behind the issue of the first tile's loads: one memory round trip at the start of the kernel, not two)
     float breg[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) breg[s] = p.bmat[s * 64 + lane];
     float bias = n < N ? p.bias[co] : 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto drain_breg = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(breg[s]));
-    asm volatile("" : "+v"(bias));
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(breg[s]));
+        asm volatile("" : "+v"(bias));
+    };
+    if constexpr (HEAD) drain_breg();
 
     // HEAD: head weights, the positive-class weight (losses.py:24-29) and this lane's partial sums
     float hwv[HEAD ? CO : 1], hbias = 0.f, hwgt = 1.f, hsum[HEAD ? CO + 2 : 1];
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(NT) void k_pgfwd(FwdArgs p) {
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) okm = tile_issue<C, TW, NT>(pre[s], mp, p.src[s], b, x0, y0, p.B, p.H, p.W);
     }
+    if constexpr (!HEAD) drain_breg();
 
     int buf = 0;
     if (DB && tile < ntiles) {
@@ -535,10 +540,6 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     if (DGRAD) {
 #pragma unroll
         for (int s = 0; s < NPASS * KSd; ++s) breg[s] = p.bmat[s * 64 + lane];
-        // drain + hide the origin of these registers (see k_pgfwd): no vmcnt waits for them inside the tile loop
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < NPASS * KSd; ++s) asm volatile("" : "+v"(breg[s]));
     }
     // dgrad epilogue: column n = (dxp, co) of pass ps -> (source, channel)
     const int dxp = n / COd, cod = n % COd;
@@ -630,6 +631,13 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         pf_issue(b, x0, y0);
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) okx = tile_issue<C, TW, NT>(prex[s], mpx, p.x[s], b, x0, y0, p.B, p.H, p.W);
+    }
+    if (DGRAD) {
+        // drain + hide the origin of the B-operand registers (see k_pgfwd): no vmcnt waits for them inside the tile loop.  Behind the
+        // issue of the first tile's loads: one memory round trip at the start of the kernel, not two.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NPASS * KSd; ++s) asm volatile("" : "+v"(breg[s]));
     }
 
     if (DB && tile < ntiles) {
