@@ -6,7 +6,8 @@
 namespace dnnca {
 
 int fast_prepare(Model* m);     // per-step operand preparation (weights -> MFMA B operands)
-int fast_finish_backward(Model* m);   // folds the weight-gradient slabs into the flat gradient vector
+int fast_finish_backward(Model* m);   // folds the weight-gradient slabs into the flat gradient vector (or defers: Model::fold_deferred)
+int fast_fold_adam(Model* m, float lr_t, const dnnca_loss_cfg& cfg, double n_label, double inv_batch_hw);   // the deferred fold + Adam + step outputs in one launch
 void fast_release(Model* m);
 unsigned long long* fast_debug_stamps(Model* m);   // tuning aid: in-kernel s_memtime stamps (DNNCA_STAMPS)    // drop the per-model plan
 // `pool`: a max-pool op fused into the conv's epilogue (fast_pool_fusable), or nullptr

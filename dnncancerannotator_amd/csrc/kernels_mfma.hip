@@ -1258,8 +1258,31 @@ struct HeadTail {
     double* scalars;
 };
 
+// ad.p != nullptr (single-replica train steps whose every gradient comes out of this launch): the thread that finishes a gradient
+// applies the Adam update to that parameter at once (g_adam's arithmetic), and the block that finishes the loss sum writes the
+// step outputs (k_finalize_scalars' job) -- the optimizer needs no launch of its own.
+struct AdamTail {
+    float* p;
+    float* m;
+    float* v;
+    float lr_t, b1, b2, eps;
+    dnnca_loss_cfg cfg;
+    double n_label, inv_batch_hw;
+    float* out5;
+};
+__device__ __forceinline__ void fold_out(float* __restrict__ grads, const AdamTail& ad, int i, float gi) {
+    grads[i] = gi;
+    if (ad.p) {
+        const float mi = ad.m[i] * ad.b1 + gi * (1.f - ad.b1);
+        const float vi = ad.v[i] * ad.b2 + (gi * gi) * (1.f - ad.b2);
+        ad.m[i] = mi;
+        ad.v[i] = vi;
+        ad.p[i] = ad.p[i] - ad.lr_t * mi / (sqrtf(vi) + ad.eps);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pg_fold(const FoldDesc* __restrict__ descs, const float* __restrict__ slabs,
-                                                 float* __restrict__ grads, int nfolds, HeadTail h) {
+                                                 float* __restrict__ grads, int nfolds, HeadTail h, AdamTail ad) {
     __shared__ float Dl[7 * 256];
     if ((int)blockIdx.x >= nfolds) {
         if (blockIdx.y != 0) return;
@@ -1274,9 +1297,22 @@ __global__ __launch_bounds__(256) void k_pg_fold(const FoldDesc* __restrict__ de
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            if (k < h.C) h.dw[k] = (float)red[0];
-            else if (k == h.C) h.dbias[0] = (float)red[0];
-            else h.scalars[3] = red[0];
+            if (k < h.C) fold_out(grads, ad, (int)(h.dw - grads) + k, (float)red[0]);       // (h.dw / h.dbias point into grads)
+            else if (k == h.C) fold_out(grads, ad, (int)(h.dbias - grads), (float)red[0]);
+            else {
+                h.scalars[3] = red[0];
+                if (ad.p) {          // the step outputs (no L2 penalty on this path: scalars[4] == 0)
+                    const double lsum = h.scalars[0];
+                    float wgt;
+                    if (ad.cfg.has_weight) wgt = ad.cfg.weight;
+                    else { const float pr = (float)(lsum / ad.n_label); wgt = pr > 0.f ? 1.0f / pr : 1.0f; }
+                    ad.out5[0] = (float)(red[0] * ad.inv_batch_hw + h.scalars[4]);
+                    ad.out5[1] = (float)(lsum / ad.n_label);
+                    ad.out5[2] = ad.cfg.weight_mul * wgt + ad.cfg.weight_add;
+                    ad.out5[3] = (float)h.scalars[1];
+                    ad.out5[4] = (float)h.scalars[2];
+                }
+            }
         }
         return;
     }
@@ -1303,12 +1339,12 @@ __global__ __launch_bounds__(256) void k_pg_fold(const FoldDesc* __restrict__ de
         // rows m = (a, e, co) are exactly the [r, r, Cout, Cin] kernel rows; column Cin is the all-ones (bias) column
         const int nwt = 4 * d.CO * d.C;
         if (o < nwt) {
-            grads[d.w_off + o] = Dl[slab_index(o / d.C, o % d.C)];
+            fold_out(grads, ad, d.w_off + o, Dl[slab_index(o / d.C, o % d.C)]);
         } else if (o < nwt + d.CO) {
             const int co = o - nwt;
             float a = 0.f;
             for (int ae = 0; ae < 4; ++ae) a += Dl[slab_index(ae * d.CO + co, d.C)];
-            grads[d.b_off + co] = a;
+            fold_out(grads, ad, d.b_off + co, a);
         }
         return;
     }
@@ -1321,11 +1357,11 @@ __global__ __launch_bounds__(256) void k_pg_fold(const FoldDesc* __restrict__ de
         int co = o % d.CO, ci = (o / d.CO) % d.C, tap = o / (d.CO * d.C);
         int dy = tap / 3, kx = tap % 3;
         for (int dx = 0; dx < d.G; ++dx) acc += Dl[slab_index(dy * WR + (dx + kx) * d.C + ci, dx * d.CO + co)];
-        grads[d.w_off + ((tap * d.cin_total) + d.ci_off + ci) * d.CO + co] = acc;
+        fold_out(grads, ad, d.w_off + ((tap * d.cin_total) + d.ci_off + ci) * d.CO + co, acc);
     } else {
         int co = o - nw;
         for (int dx = 0; dx < d.G; ++dx) acc += Dl[slab_index(3 * WR, dx * d.CO + co)];
-        grads[d.b_off + co] = acc;
+        fold_out(grads, ad, d.b_off + co, acc);
     }
 }
 
@@ -1412,6 +1448,8 @@ struct PgPlan {                      // per-model table built lazily on the firs
     size_t slab_floats = 0;
     std::map<std::pair<const Op*, int>, int> wslot;  // (op, source) -> index into folds (transposed convs: source 0)
     int fold_chunks = 0;
+    int64_t fold_outputs = 0;      // gradient elements k_pg_fold writes (all folds); with the head's C + 1: == nT when the plan covers the model
+    HeadTail pending_head{};       // fast_finish_backward -> fast_fold_adam
     int nblocks_cap = 512;
     bool nblocks_forced = false;       // DNNCA_NBLOCKS (tuning aid) overrides the occupancy-derived grids
     int nthreads = 512;
@@ -1491,6 +1529,7 @@ static int build_plan(Model* m, PgPlan& pl) {
             pl.folds.push_back(f);
             int outs = 9 * CA * CO + CO;
             if (outs > max_out) max_out = outs;
+            pl.fold_outputs += 9 * CA * CO + (f.b_off >= 0 ? CO : 0);
         }
     }
     for (const Op& o : m->ops) {
@@ -1508,6 +1547,7 @@ static int build_plan(Model* m, PgPlan& pl) {
         pl.folds.push_back(f);
         int outs = 4 * f.CO * f.C + f.CO;
         if (outs > max_out) max_out = outs;
+        pl.fold_outputs += outs;
     }
     pl.built = true;
     if (const char* e = getenv("DNNCA_DB")) pl.double_buffer = atoi(e) != 0;            // tuning aid
@@ -2056,9 +2096,29 @@ int fast_finish_backward(Model* m) {
         extra = h.C + 2;
         m->head_pending.partials = nullptr;
     }
+    // single-replica train step whose every gradient (and the loss) comes out of this launch: wait for optimizer_step and let the
+    // fold apply Adam as well (fast_fold_adam)
+    if (extra && !m->comm && !m->dry && m->merged_launches() && m->desc.l2 == 0.f && pl.fold_outputs + h.C + 1 == m->nT &&
+        !getenv("DNNCA_NO_FOLD_ADAM")) {
+        m->fold_deferred = true;
+        pl.pending_head = h;
+        return DNNCA_OK;
+    }
     LAUNCH(m, "pg_fold", 0, 0,
            hipLaunchKernelGGL(k_pg_fold, dim3((unsigned)pl.folds.size() + extra, pl.fold_chunks), dim3(256), 0, m->stream,
-                              pl.folds_dev, pl.slabs, m->g, (int)pl.folds.size(), h));
+                              pl.folds_dev, pl.slabs, m->g, (int)pl.folds.size(), h, AdamTail{}));
+    return DNNCA_OK;
+}
+
+// the deferred fold of fast_finish_backward with the Adam update (and the step outputs) in the same launch
+int fast_fold_adam(Model* m, float lr_t, const dnnca_loss_cfg& cfg, double n_label, double inv_batch_hw) {
+    PgPlan& pl = g_plans[m];
+    const HeadTail h = pl.pending_head;
+    m->fold_deferred = false;
+    AdamTail ad{m->p, m->m, m->v, lr_t, m->beta1, m->beta2, m->eps, cfg, n_label, inv_batch_hw, m->out5};
+    LAUNCH(m, "pg_fold_adam", 28.0 * m->nT, 10.0 * m->nT,
+           hipLaunchKernelGGL(k_pg_fold, dim3((unsigned)pl.folds.size() + h.C + 2, pl.fold_chunks), dim3(256), 0, m->stream,
+                              pl.folds_dev, pl.slabs, m->g, (int)pl.folds.size(), h, ad));
     return DNNCA_OK;
 }
 

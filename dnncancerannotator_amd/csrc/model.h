@@ -104,6 +104,7 @@ struct Model {
     int label_part_nblk = 0;
     bool label_part_valid = false;
     const Op* first_done = nullptr;      // the first conv whose weight gradient rode in the backward launch of the conv behind it (k_first3)
+    bool fold_deferred = false;          // the slab fold waits for optimizer_step: fold + Adam + step outputs in one launch (fast_fold_adam)
     const Op* tail_done = nullptr;       // the conv whose backward already ran inside the forward pass (fast_tail3)
     struct PoolFold { const Op* conv = nullptr; const Op* pool = nullptr; } pool_fold;     // fast_pool_fold -> fast_conv_bwd hand-over
     struct HeadInConv { const float* y = nullptr; dnnca_loss_cfg cfg; bool requested = false, done = false, labels_done = false; } head_in_conv;

@@ -387,6 +387,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
     DN_TRY(ig_prepare(this));
     head_in_conv.done = false;
     tail_done = first_done = nullptr;
+    fold_deferred = false;
     // the head will ride in the last conv's epilogue: it needs the label statistics (positive rate) of this step, so they go first
     // (pg_prep has just zeroed the scalars)
     bool head_in_conv_ok = head_in_conv.requested && !generic && (step_init_done || dry) && head_defer_ok && ops.size() >= 2 &&
@@ -742,6 +743,11 @@ int Model::optimizer_step(float lr) {
     iterations += dry ? 0 : 1;
     double t = (double)(dry ? 1 : iterations);
     float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+    if (fin_pending.on && fold_deferred) {
+        fin_pending.on = false;
+        return fast_fold_adam(this, lr_t, fin_pending.cfg, fin_pending.n_label, fin_pending.inv_batch_hw);
+    }
+    if (fold_deferred) { set_error("internal: deferred gradient fold without a single-replica optimizer step"); return DNNCA_ESTATE; }
     if (fin_pending.on) {
         fin_pending.on = false;
         LAUNCH(this, "g_adam", 28.0 * nT, 10.0 * nT,
