@@ -475,6 +475,42 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
     m.close()
 
 
+@pytest.mark.parametrize('B, H, W', [(1, 8, 64), (2, 24, 120), (5, 32, 248), (3, 88, 504), (1, 512, 512), (11, 64, 64)])
+def test_strip_kernels_match_the_per_layer_kernels(gpu, monkeypatch, B, H, W):
+    """The column-strip kernels (k_tail3, k_first3, k_first3_fwd, k_up3_fwd) against the per-layer / tile kernels they replace, on
+    shapes that stress their bookkeeping: one chunk, partial last strips, odd chunk heights, one image, more images than XCDs.
+    Same device, same weights: loss, probabilities and every gradient tensor (float32 sums in two different orders)."""
+    from dnncancerannotator_amd.synthetic import synthetic_batch
+    x, y = synthetic_batch(B, H, W, 1)
+    spec = O.ModelSpec('unet', 1, **UNET)
+    rng = np.random.default_rng(5)
+
+    def run():
+        m = gpu.DeviceModel('unet', 1, H, W, B, **UNET)
+        m.init_glorot(seed=2)
+        p0 = m.get_params()
+        m.set_params((p0 + np.random.default_rng(7).uniform(-0.05, 0.05, p0.shape)).astype(np.float32))
+        out = m.train_step(x, y, 0.0, m.loss_cfg(weight_mul=3.0))
+        g = m.get_grads()
+        prob = m.forward(x, training=False)
+        plan = set(r[0] for r in m.plan())
+        m.close()
+        return out.loss, g, prob, plan
+
+    l1, g1, p1, plan1 = run()
+    for k in ('DNNCA_NO_TAIL3', 'DNNCA_NO_FIRST3', 'DNNCA_NO_FIRST3F', 'DNNCA_NO_UP3F'):
+        monkeypatch.setenv(k, '1')
+    l0, g0, p0, plan0 = run()
+    assert {'tail3_3x1_3', 'first3_fwd', 'up3_fwd'} <= plan1 and not ({'tail3_3x1_3', 'first3_fwd', 'up3_fwd', 'first3_bwd'} & plan0), (plan1, plan0)
+    assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
+    assert np.abs(np.asarray(p1) - np.asarray(p0)).max() <= 2e-5
+    # two float32 paths sum the convolutions in different orders: a pooling window whose two largest values agree to the last bit or
+    # two routes its gradient differently (one pixel of 256 K at the first level: measured 1.6e-4 of encoder.down1.conv0.kernel's
+    # scale on the one-image shape, <= 1e-4 everywhere else) -- 3 x FULL_TOL; a mis-indexed strip, chunk or halo is off by >= 1e-2
+    Hp.assert_grads_per_tensor(spec, g1, g0, 3 * FULL_TOL, what='strip vs per-layer kernels')
+    del rng
+
+
 def test_rccl_one_rank_rehearsal(gpu):
     """The RCCL calls of the DP path (unique id, communicator, gradient all-reduce on the step's stream, broadcast,
     state average, host all-reduce) on a one-rank communicator: a sum over one rank is the identity, so weights, BN
