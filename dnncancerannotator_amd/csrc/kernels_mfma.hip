@@ -428,6 +428,14 @@ struct BwdArgs {
     const float* pf_dpool;           // gradient of the pooled tensor [B, H/2, W/2, CO]
     const unsigned char* pf_idx;     // window position of every maximum [B, H/2, W/2, CO]
     float pf_alpha;                  // slope of act'
+    // TCF (the two-source 3-channel conv whose first source is the output of a 6 -> 3 transposed conv): the gradient of that source
+    // stays in LDS and the transposed conv's whole backward follows in the same launch (components.py:118-127)
+    const float* tc_in;      // the transposed conv's input [B, H/2, W/2, 6]
+    float* tc_din;           // its gradient
+    const float* tc_w;       // kernel [2][2][3][6]
+    float* tc_slabs;         // weight-gradient slabs of the transposed conv [NBUCKET][256]
+    int tc_mask;             // multiply tc_din by act'(tc_in)
+    float tc_alpha;
     int dbg;                 // tuning aid (DNNCA_DBG): bit 0 skip the data-gradient phase, bit 1 skip the weight-gradient phase
     unsigned long long* stamps;   // tuning aid (DNNCA_STAMPS): [block][tile slot 0..3][8] s_memtime stamps of wave 0
 };
@@ -473,9 +481,10 @@ __device__ __forceinline__ int slab_index(int mrow, int n);
 // data-gradient MFMAs for the whole tile, waves [NW/2, NW) walk down pixel columns of the same staged tiles with a sliding
 // 3 x 3 x C window in registers and keep dW[dy][kx][ci][co] + db[co] in 84 accumulators per lane.  Every SIMD hosts one wave of
 // each kind (waves are dealt to SIMDs cyclically), so the two pipes run side by side.
-template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB, bool VW = false, bool PF = false>
+template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB, bool VW = false, bool PF = false, bool TCF = false>
 __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs p) {
     constexpr int NW = NT / 64;
+    static_assert(!TCF || (VW && NSRC == 2 && C == 3 && CO == 3), "TCF rides in the two-source 3-channel VW kernel");
     static_assert(!PF || (NSRC == 1 && C == CO && DGRAD && !VW && !DB), "PF: single-source C -> C conv with data gradient");
     static_assert(!VW || (C == 3 && CO == 3 && NT == 512 && DGRAD), "VW: 3 -> 3 channels, eight waves, with data gradient");
     constexpr int NWD = VW ? NW / 2 : NW;          // waves that run the data gradient
@@ -491,8 +500,12 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     // PF: pooled-gradient tile (floats) and window-position tile (bytes), TH/2 + 2 rows of TW/2 + 2 pixels, lead as for a halo-1 tile
     constexpr int PFR = TH / 2 + 2, PFW = Wc::TW / 2 + 2, PFLEAD = (4 - CO % 4) % 4;
     constexpr int PFLS = (PFLEAD + PFW * CO + 3) / 4 * 4, PFN4 = PF ? PFR * PFLS / 4 : 0, PFLI = PFLS / 4, PFNI = PF ? PFR * PFLI : 0;
-    __shared__ float4 lds4[MAIN4 + NW * 48 + 1 + PFN4 + (PFNI + 3) / 4];       // staged tiles (reused for the final reduction) + output rows + constants
+    // TCF: gradient of the transposed conv's output for the whole tile [TH rows][4 column blocks][32 pixels x 3] + its kernel (72)
+    constexpr int TCF4 = TCF ? TH * 4 * 24 + 18 : 0;
+    __shared__ float4 lds4[MAIN4 + NW * 48 + 1 + PFN4 + (PFNI + 3) / 4 + TCF4];       // staged tiles (reused for the final reduction) + output rows + constants
     float* orow = reinterpret_cast<float*>(lds4 + MAIN4) + (threadIdx.x >> 6) * 192;
+    float4* dta4 = lds4 + MAIN4 + NW * 48 + 1 + PFN4 + (PFNI + 3) / 4;
+    float* tcw = reinterpret_cast<float*>(dta4 + TH * 4 * 24);
     float* pf_dp = reinterpret_cast<float*>(lds4 + MAIN4 + NW * 48 + 1);
     unsigned* pf_ix = reinterpret_cast<unsigned*>(lds4 + MAIN4 + NW * 48 + 1 + PFN4);
     constexpr int NPS = PF ? (PFN4 + NT - 1) / NT : 1;       // prefetch slots per thread for the pooled tiles (PFNI = PFN4)
@@ -507,6 +520,15 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     // padding columns): the MFMA operands are then plain LDS reads, no per-MFMA select
     float* cst = reinterpret_cast<float*>(lds4 + MAIN4 + NW * 48);
     if (threadIdx.x == 0) { cst[0] = 1.0f; cst[1] = 0.0f; }
+    if constexpr (TCF) {
+        if (threadIdx.x < 72) tcw[threadIdx.x] = p.tc_w[threadIdx.x];
+    }
+    // TCF: dWt[(a, e, co)][ci] and dbt[co] of this lane's pooled pixels (data-gradient waves)
+    float tacc[TCF ? 72 : 1], tbias[TCF ? 3 : 1];
+#pragma unroll
+    for (int i = 0; i < (TCF ? 72 : 1); ++i) tacc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (TCF ? 3 : 1); ++i) tbias[i] = 0.f;
     const float* ldsf = reinterpret_cast<const float*>(lds4);
     constexpr int CST1 = (MAIN4 + NW * 48) * 4, CST0 = CST1 + 1;     // absolute float indices of the constants
     // wgrad A-operand addressing: row mrow = (dy, j) of the group's window; last valid row is the all-ones bias row.
@@ -666,6 +688,17 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         const float* gl = ldsf + GOFF;
         const float* xl = ldsf + XOFF;
         STAMP(1);
+        // TCF: a data-gradient wave owns the column block tx = wave of the tile (32 pixels, all TH rows) = 16 x TH/2 pixels of the
+        // transposed conv's input, one per lane; their 6 channels are fetched now (ahead of the prefetch: vmcnt retires in order)
+        float tin[TCF ? 6 : 1];
+        if constexpr (TCF) {
+            if (wave < NWD) {
+                const int pr = lane >> 4, pc = lane & 15;
+                const float* ip = p.tc_in + ((((size_t)b * (p.H >> 1) + (y0 >> 1) + pr) * (p.W >> 1)) + (x0 >> 1) + wave * 16 + pc) * 6;
+#pragma unroll
+                for (int ci = 0; ci < 6; ++ci) tin[ci] = ip[ci];
+            }
+        }
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
@@ -731,7 +764,10 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
                         else if constexpr (SPL == 2) { dxs = sp ? p.dx[1] : p.dx[0]; accs = sp ? p.acc[1] : p.acc[0]; masks = sp ? p.mask[1] : p.mask[0]; }
                         else { dxs = p.dx[0]; accs = p.acc[0]; masks = p.mask[0]; }
                         const int f0 = (x0 + tx * 16 * Gd) * C + 4 * i4;        // float index within the image row
-                        if (lane < SPL * PER4 && f0 < p.W * C && y < p.H) {
+                        if (TCF && sp == 0) {
+                            // the first source's gradient (= the transposed conv's output gradient) stays in LDS (whole tiles only)
+                            if (lane < PER4) dta4[(ty * 4 + tx) * 24 + i4] = reinterpret_cast<const float4*>(orow)[lane];
+                        } else if (lane < SPL * PER4 && f0 < p.W * C && y < p.H) {
                             float4 v = reinterpret_cast<const float4*>(orow)[lane];
                             float* dst = dxs + ((size_t)b * p.H + y) * p.W * C + f0;
                             if (accs) {
@@ -751,6 +787,44 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
+            }
+        }
+        if constexpr (TCF) {
+            // ---- transposed conv backward on the data-gradient waves: lane = one input pixel (pr, pc) of this wave's column block; its
+            // 2 x 2 output pixels' gradients are in the LDS tile this wave has just written (DS operations of one wave execute in order)
+            if (wave < NWD && !(DBG_FLAGS(p) & 1)) {
+                __builtin_amdgcn_wave_barrier();
+                const int pr = lane >> 4, pc = lane & 15;
+                const float* dt = reinterpret_cast<const float*>(dta4);
+                float din[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float d6[6];                 // (e, co) of output row 2 pr + a, pixels 2 pc, 2 pc + 1
+                    const float* rp = dt + (((2 * pr + a) * 4 + wave) * 24) * 4 + (2 * pc) * 3;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) d6[i] = rp[i];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int co = 0; co < 3; ++co) {
+                            const float d = d6[e * 3 + co];
+                            tbias[co] += d;
+                            const float* wr = tcw + ((a * 2 + e) * 3 + co) * 6;      // uniform address: broadcast reads
+#pragma unroll
+                            for (int ci = 0; ci < 6; ++ci) {
+                                din[ci] = fmaf(d, wr[ci], din[ci]);
+                                tacc[((a * 2 + e) * 3 + co) * 6 + ci] = fmaf(d, tin[ci], tacc[((a * 2 + e) * 3 + co) * 6 + ci]);
+                            }
+                        }
+                }
+                if (p.tc_mask) {
+#pragma unroll
+                    for (int ci = 0; ci < 6; ++ci) din[ci] *= tin[ci] > 0.f ? 1.0f : p.tc_alpha;
+                }
+                float* op = p.tc_din + ((((size_t)b * (p.H >> 1) + (y0 >> 1) + pr) * (p.W >> 1)) + (x0 >> 1) + wave * 16 + pc) * 6;
+#pragma unroll
+                for (int ci = 0; ci < 6; ++ci) op[ci] = din[ci];
+                __builtin_amdgcn_wave_barrier();
             }
         }
         STAMP(3);
@@ -885,8 +959,29 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
                 // one source: wave wv < 3 holds kernel row wv (elements wv*27 ..), wave 3 the bias (81 .. 83)
                 if (lane == 63 && (NSRC == 2 || wv < 3 || i < 3)) red[NSRC == 2 ? wv * 84 + i : wv * 27 + i] = t;
             }
+        } else if constexpr (TCF) {
+            // the data-gradient waves: totals of the transposed conv's weight / bias gradient behind the four 84-float rows
+#pragma unroll
+            for (int i = 0; i < 72; ++i) {
+                const float t = wave_total_l63(tacc[i]);
+                if (lane == 63) red[4 * 84 + wave * 75 + i] = t;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float t = wave_total_l63(tbias[i]);
+                if (lane == 63) red[4 * 84 + wave * 75 + 72 + i] = t;
+            }
         }
         __syncthreads();
+        if constexpr (TCF) {
+            if (tid < 75) {
+                const float* r2 = red + 4 * 84;
+                const float v = (r2[tid] + r2[75 + tid]) + (r2[150 + tid] + r2[225 + tid]);
+                // rows (a, e, co), columns ci; the bias in column 6 of its (a = 0, e = 0, co) row (the fold sums that column over (a, e))
+                const int mrow = tid < 72 ? tid / 6 : tid - 72, col = tid < 72 ? tid % 6 : 6;
+                atomicAdd(p.tc_slabs + (size_t)(blockIdx.x % NBUCKET) * 256 + slab_index(mrow, col), v);
+            }
+        }
         const int bucket = blockIdx.x % NBUCKET;
         for (int i = tid; i < NSRC * 84; i += NT) {
             const int s = i / 84, e = i - s * 84;
@@ -1815,6 +1910,25 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
             LAUNCH(m, "pgbwd_3x1_3", bytes, fl,
                    hipLaunchKernelGGL((k_pgbwd<3, 1, 3, true, 512, false, true>), dim3(g), dim3(512), 0, m->stream, a));
         } else {
+            // the first source is the output of a 6 -> 3 transposed conv (the last decoder block): that layer's backward rides along
+            const size_t oi = (size_t)(&o - m->ops.data());
+            Op* tc = oi >= 1 && oi < m->ops.size() ? &m->ops[oi - 1] : nullptr;
+            auto tw = tc ? pl.wslot.find({tc, 0}) : pl.wslot.end();
+            if (tc && !getenv("DNNCA_NO_TCF") && tc->type == OP_TCONV && tc->k == 2 && tc->inA.d.C == 6 && tc->out.d.C == 3 &&
+                tc->out.d.p == o.inA.d.p && tw != pl.wslot.end() && fast_tconv_supported(m, *tc) && !tc->accA && !o.accA && !o.maskA &&
+                dense(tc->inA.d) && dense(tc->inA.g) && dense(o.inA.d) && tc->inA.d.H * 2 == a.H && tc->inA.d.W * 2 == a.W && a.W % 128 == 0 &&
+                a.H % TH == 0) {
+                a.tc_in = tc->inA.d.p; a.tc_din = tc->inA.g.p; a.tc_w = m->p + tc->w_off;
+                a.tc_slabs = pl.slabs + pl.folds[tw->second].slab_off;
+                a.tc_mask = tc->maskA; a.tc_alpha = tc->mask_alpha;
+                static const int fit = resident_blocks(k_pgbwd<3, 2, 3, true, 512, false, true, false, true>, 1 << 20);
+                const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);
+                const double tb = 4.0 * ((double)B * a.H * a.W * 3 + (double)B * (a.H / 2) * (a.W / 2) * 6);      // the transposed conv's out + in
+                LAUNCH(m, "pgbwd_tc_3x2_3", bytes + 2 * tb, fl + 4.0 * B * a.H * a.W * 3 * 6,
+                       hipLaunchKernelGGL((k_pgbwd<3, 2, 3, true, 512, false, true, false, true>), dim3(g), dim3(512), 0, m->stream, a));
+                m->tconv_done = tc;
+                return true;
+            }
             static const int fit = resident_blocks(k_pgbwd<3, 2, 3, true, 512, false, true>, 1 << 20);
             const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);
             LAUNCH(m, "pgbwd_3x2_3", bytes, fl,

@@ -103,6 +103,7 @@ struct Model {
     float* label_part = nullptr;
     int label_part_nblk = 0;
     bool label_part_valid = false;
+    const Op* tconv_done = nullptr;      // the transposed conv whose backward rode in the launch of the conv behind it (k_pgbwd TCF)
     const Op* first_done = nullptr;      // the first conv whose weight gradient rode in the backward launch of the conv behind it (k_first3)
     bool fold_deferred = false;          // the slab fold waits for optimizer_step: fold + Adam + step outputs in one launch (fast_fold_adam)
     const Op* tail_done = nullptr;       // the conv whose backward already ran inside the forward pass (fast_tail3)

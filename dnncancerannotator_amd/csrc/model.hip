@@ -386,7 +386,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
     DN_TRY(fast_prepare(this));
     DN_TRY(ig_prepare(this));
     head_in_conv.done = false;
-    tail_done = first_done = nullptr;
+    tail_done = first_done = tconv_done = nullptr;
     fold_deferred = false;
     // the head will ride in the last conv's epilogue: it needs the label statistics (positive rate) of this step, so they go first
     // (pg_prep has just zeroed the scalars)
@@ -664,6 +664,10 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 case OP_TCONV: {
                     double ob = 4.0 * nelem(B, o.out.d), ib = 4.0 * nelem(B, o.inA.d);
                     double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
+                    if (tconv_done == &o) {                         // its backward rode in the previous launch (k_pgbwd TCF)
+                        tconv_done = nullptr;
+                        break;
+                    }
                     if (!generic && (fast_tconv_bwd(this, B, o, ob, ib, flops) || ig_tconv_bwd(this, B, o, ob, ib, flops))) break;
                     if (!all_f32(o)) return DNNCA_ESTATE;
                     if (o.maskA) { set_error("internal: masked transposed-conv gradient has no tuned kernel"); return DNNCA_ESTATE; }
