@@ -17,9 +17,11 @@ from collections import defaultdict
 def short_name(k):
     """HIP kernel name -> the LAUNCH name used by libdnnca's profile table / bench.py."""
     k = re.sub(r'^void ', '', k)
-    m = re.match(r'dnnca::k_pgbwd<(\d+), (\d+), (\d+), (true|false)', k)
+    m = re.match(r'dnnca::k_pgbwd<(\d+), (\d+), (\d+), (true|false)((?:, \w+)*)>', k)
     if m:
-        return 'pgbwd_%s%sx%s_%s' % ('' if m.group(4) == 'true' else 'w_', m.group(1), m.group(2), m.group(3))
+        rest = [t.strip() for t in m.group(5).split(',') if t.strip()]      # NT, DB, VW, PF, TCF
+        kind = 'tc_' if len(rest) >= 5 and rest[4] == 'true' else ('pool_' if len(rest) >= 4 and rest[3] == 'true' else '')
+        return 'pgbwd_%s%s%sx%s_%s' % ('' if m.group(4) == 'true' else 'w_', kind, m.group(1), m.group(2), m.group(3))
     m = re.match(r'dnnca::k_pgfwd<(\d+), (\d+), (\d+), \d+, (?:true|false)(, true)?>', k)
     if m:
         return 'pgfwd_%s%sx%s_%s' % ('head_' if m.group(4) else '', m.group(1), m.group(2), m.group(3))
