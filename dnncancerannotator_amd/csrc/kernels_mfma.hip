@@ -1075,20 +1075,34 @@ struct StepInit {
     unsigned na4, nb4;
 };
 
-__global__ __launch_bounds__(256) void k_pg_prep(const int* __restrict__ index, const float* __restrict__ params,
-                                                 float* __restrict__ bmat, int n, int nprep, StepInit z) {
-    if ((int)blockIdx.x >= nprep) {
-        const unsigned T = (gridDim.x - nprep) * 256u, i0 = (blockIdx.x - nprep) * 256u + threadIdx.x;
+struct PrepRide {          // k_pg_prep's arguments when the preparation rides in another kernel's launch (blocks past that kernel's own)
+    const int* index;
+    const float* params;
+    float* bmat;
+    int n, nprep, nblocks;     // nblocks = nprep + zeroing blocks (0: nothing rides)
+    StepInit z;
+};
+
+// block `blk` of `nblocks` preparation blocks (256 threads)
+__device__ __forceinline__ void pg_prep_body(const int* __restrict__ index, const float* __restrict__ params, float* __restrict__ bmat,
+                                             int n, int nprep, const StepInit& z, int blk, int nblocks) {
+    if (blk >= nprep) {
+        const unsigned T = (unsigned)(nblocks - nprep) * 256u, i0 = (unsigned)(blk - nprep) * 256u + threadIdx.x;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         for (unsigned i = i0; i < z.na4; i += T) z.a[i] = zero;
         for (unsigned i = i0; i < z.nb4; i += T) z.b[i] = zero;
         if (i0 < 8) z.scalars[i0] = i0 == 1 ? (double)INFINITY : (i0 == 2 ? -(double)INFINITY : 0.0);   // see k_step_init
         return;
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blk * 256 + threadIdx.x;
     if (i >= n) return;
     const int j = index[i];
     bmat[i] = j >= 0 ? params[j] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_pg_prep(const int* __restrict__ index, const float* __restrict__ params,
+                                                 float* __restrict__ bmat, int n, int nprep, StepInit z) {
+    pg_prep_body(index, params, bmat, n, nprep, z, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace dnnca
@@ -1543,6 +1557,7 @@ struct PgPlan {                      // per-model table built lazily on the firs
     size_t slab_floats = 0;
     std::map<std::pair<const Op*, int>, int> wslot;  // (op, source) -> index into folds (transposed convs: source 0)
     int fold_chunks = 0;
+    PrepRide prep{};                // this step's k_pg_prep arguments (fast_prepare)
     int64_t fold_outputs = 0;      // gradient elements k_pg_fold writes (all folds); with the head's C + 1: == nT when the plan covers the model
     HeadTail pending_head{};       // fast_finish_backward -> fast_fold_adam
     int nblocks_cap = 512;
@@ -1696,6 +1711,18 @@ int fast_prepare(Model* m) {
         nz = (int)((z.na4 + z.nb4 + 1023) / 1024);
         nz = nz < 1 ? 1 : (nz > 1024 ? 1024 : nz);
         m->step_init_done = true;
+    }
+    pl.prep = PrepRide{pl.bindex, m->p, pl.bmat, pl.bmat_n, nprep, nprep + nz, z};
+    if (nz && !getenv("DNNCA_NO_PREP_RIDE")) {
+        // train step: the first launch of the forward pass decides -- the first encoder block's strip kernel takes the preparation
+        // along as extra blocks (it needs none of its results); any other launch flushes it first (LAUNCH)
+        m->prep_flush = [](Model* mm) {
+            PgPlan& q = g_plans[mm];
+            LAUNCH(mm, "pg_prep", 0, 0,
+                   hipLaunchKernelGGL(k_pg_prep, dim3(q.prep.nblocks), dim3(256), 0, mm->stream, q.prep.index, q.prep.params, q.prep.bmat,
+                                      q.prep.n, q.prep.nprep, q.prep.z));
+        };
+        return DNNCA_OK;
     }
     LAUNCH(m, "pg_prep", 0, 0,
            hipLaunchKernelGGL(k_pg_prep, dim3(nprep + nz), dim3(256), 0, m->stream, pl.bindex, m->p, pl.bmat, pl.bmat_n, nprep, z));
@@ -2058,6 +2085,18 @@ bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsig
     a.nchunks = nchunks;
     const int nblk = (B * nchunks * a.nstrips + 3) / 4;
     if (nblk > 2048) return false;
+    a.nstrip_blocks = nblk;
+    int nride = 0;
+    if (m->prep_flush) {            // the step's operand preparation rides in this launch (blocks nblk ..)
+        m->prep_flush = nullptr;
+        a.prep = g_plans[m].prep;
+        nride = a.prep.nblocks;
+    }
+    if (nride) {
+        LAUNCH(m, "first3_fwd", bytes, flops, hipLaunchKernelGGL((k_first3_fwd<0, 27>), dim3(nblk + nride), dim3(256), 0, m->stream, a));
+        *nblocks = nblk;
+        return true;
+    }
     if (wps == 3)
         LAUNCH(m, "first3_fwd", bytes, flops, hipLaunchKernelGGL((k_first3_fwd<0, 27, 3>), dim3(nblk), dim3(256), 0, m->stream, a));
     else

@@ -105,6 +105,9 @@ struct Model {
     bool label_part_valid = false;
     const Op* tconv_done = nullptr;      // the transposed conv whose backward rode in the launch of the conv behind it (k_pgbwd TCF)
     const Op* first_done = nullptr;      // the first conv whose weight gradient rode in the backward launch of the conv behind it (k_first3)
+    // the step's operand preparation (k_pg_prep: B operands + zeroing) waits for the first launch of the forward pass: the first
+    // encoder block's strip kernel takes it along as extra blocks; any other launch flushes it first (LAUNCH)
+    void (*prep_flush)(Model*) = nullptr;
     bool fold_deferred = false;          // the slab fold waits for optimizer_step: fold + Adam + step outputs in one launch (fast_fold_adam)
     const Op* tail_done = nullptr;       // the conv whose backward already ran inside the forward pass (fast_tail3)
     struct PoolFold { const Op* conv = nullptr; const Op* pool = nullptr; } pool_fold;     // fast_pool_fold -> fast_conv_bwd hand-over
@@ -161,6 +164,11 @@ struct Model {
 // A launch is only "open" for profiling between begin() and end(); focus mode leaves other launches untouched.
 #define LAUNCH(m, name, bytes, flops, call)                \
     do {                                                   \
+        if ((m)->prep_flush) {      /* a deferred operand preparation that no launch has taken along: it goes first */ \
+            auto flush_ = (m)->prep_flush;                 \
+            (m)->prep_flush = nullptr;                     \
+            flush_(m);                                     \
+        }                                                  \
         bool prof_open_ = false;                           \
         if ((m)->dry || (m)->prof_mode) {                  \
             size_t before_ = (m)->recs.size();             \

@@ -615,18 +615,24 @@ struct FirstFwdArgs {
     float* pool;             // [B, H/2, W/2, 3]
     unsigned char* pool_idx; // [B, H/2, W/2, 3] window position (0..3, row-major) of each pooled value's FIRST maximum, or nullptr
     const float* labels;     // [B, H, W] or nullptr
-    float* label_part;       // [gridDim.x][4] per-block (sum, min, max, -)
+    float* label_part;       // [nstrip_blocks][4] per-block (sum, min, max, -)
     int B, H, W;
     int nstrips, nchunks;
+    int nstrip_blocks;       // blocks [0, nstrip_blocks) walk strips; the blocks behind them run the step's operand preparation
+    PrepRide prep;           // (k_pg_prep's job: the first launch of a train step takes it along; prep.nblocks == 0: nothing rides)
 };
 
 template <int WS0, int WS1, int WPS = 2>      // how many of the 27 / 81 kernel weights are scalar-register operands (the rest: vector registers); waves per SIMD
 __global__ __launch_bounds__(256, WPS) void k_first3_fwd(FirstFwdArgs p) {
     constexpr int PFD = 6;           // rows in flight per lane (8 bytes each: the steps are short, three rows ahead did not cover the latency)
     __shared__ float red[32];
+    if ((int)blockIdx.x >= p.nstrip_blocks) {
+        pg_prep_body(p.prep.index, p.prep.params, p.prep.bmat, p.prep.n, p.prep.nprep, p.prep.z, (int)blockIdx.x - p.nstrip_blocks, p.prep.nblocks);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
-    const int nblk = gridDim.x;
+    const int nblk = p.nstrip_blocks;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int ntasks = p.B * p.nchunks * p.nstrips;
     const int t0 = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
