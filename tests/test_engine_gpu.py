@@ -477,7 +477,9 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
 
 @pytest.mark.parametrize('B, H, W', [(1, 8, 64), (2, 24, 120), (5, 32, 248), (3, 88, 504), (1, 512, 512), (11, 64, 64)])
 def test_strip_kernels_match_the_per_layer_kernels(gpu, monkeypatch, B, H, W):
-    """The column-strip kernels (k_tail3, k_first3, k_first3_fwd, k_up3_fwd) against the per-layer / tile kernels they replace, on
+    """The column-strip kernels (k_tail3, k_first3, k_first3_fwd, k_up3_fwd) and the ride-along launches (transposed-conv backward in
+    the two-source conv's launch, Adam in the slab fold, operand preparation in the first strip launch) against the per-layer / tile
+    kernels and separate launches they replace, on
     shapes that stress their bookkeeping: one chunk, partial last strips, odd chunk heights, one image, more images than XCDs.
     Same device, same weights: loss, probabilities and every gradient tensor (float32 sums in two different orders)."""
     from dnncancerannotator_amd.synthetic import synthetic_batch
@@ -498,7 +500,7 @@ def test_strip_kernels_match_the_per_layer_kernels(gpu, monkeypatch, B, H, W):
         return out.loss, g, prob, plan
 
     l1, g1, p1, plan1 = run()
-    for k in ('DNNCA_NO_TAIL3', 'DNNCA_NO_FIRST3', 'DNNCA_NO_FIRST3F', 'DNNCA_NO_UP3F'):
+    for k in ('DNNCA_NO_TAIL3', 'DNNCA_NO_FIRST3', 'DNNCA_NO_FIRST3F', 'DNNCA_NO_UP3F', 'DNNCA_NO_TCF', 'DNNCA_NO_FOLD_ADAM', 'DNNCA_NO_PREP_RIDE'):
         monkeypatch.setenv(k, '1')
     l0, g0, p0, plan0 = run()
     assert {'tail3_3x1_3', 'first3_fwd', 'up3_fwd'} <= plan1 and not ({'tail3_3x1_3', 'first3_fwd', 'up3_fwd', 'first3_bwd'} & plan0), (plan1, plan0)
