@@ -24,7 +24,7 @@ bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsig
                      double bytes, double flops, int* nblocks);      // first encoder block forward as one column-strip launch
 bool fast_up3_fwd(Model* m, int B, size_t oi);     // last decoder block: transposed conv + two-source conv forward in one column-strip launch
 bool fast_head_in_conv_possible(Model* m);      // would fast_conv_fwd_head take the conv that feeds the head?
-bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid);
+bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid, int* consumed = nullptr);
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 // kernels_first.hip: the one-channel-input 3x3 convs (first layer of every encoder)
 bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);   // bn_next as for ig_conv_fwd

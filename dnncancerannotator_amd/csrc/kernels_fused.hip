@@ -408,9 +408,13 @@ struct UpArgs {
     float* y1;               // conv1 output
     int B, H, W, tiles_x, tiles_y;
     float alpha0, alpha1;
+    // NF > 0: the next Upsample block's Conv2DTranspose(F -> NF) rides in the epilogue (its input is this block's output tile)
+    const float* nwt;        // [2][2][NF][F]
+    const float* nbt;        // [NF]
+    float* nup;              // [B, 2H, 2W, NF]
 };
 
-template <int CIN, int F, int TW, int TH, int NT, int MINW>
+template <int CIN, int F, int TW, int TH, int NT, int MINW, int NF = 0>
 __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
     constexpr int NW = NT / 64;
     constexpr int G = 12 / F, RG = even_up(cdiv(TW + 5, G)), RG2 = TW / G, MPR = RG2 / 16;
@@ -473,6 +477,20 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
         }
     }
 
+    // riding Conv2DTranspose(F -> NF): per output-row parity a one N block of columns (e, co), K = F
+    constexpr int NFX = NF > 0 ? NF : 1, KT2 = F / 4;
+    static_assert(NF == 0 || (2 * NF <= 16 && F % 4 == 0 && (16 * 2 * NF) % 4 == 0 && 16 * 2 * NF <= 64 * 4), "riding tconv shape");
+    float tw2[2][KT2], tb2 = 0.f;
+    if constexpr (NF > 0) {
+        const int n = lane & 15;
+        const bool nv = n < 2 * NF;
+        tb2 = nv ? p.nbt[n % NFX] : 0.f;
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int k = 0; k < KT2; ++k) tw2[a2][k] = nv ? p.nwt[(a2 * 2 * NF + n) * F + 4 * k + (lane >> 4)] : 0.f;
+    }
+
     for (int i = tid; i < LN / 4 + 2 * TU::N4 + T1::N4; i += NT) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pin_breg<KS0>(breg0);
@@ -483,6 +501,13 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
         asm volatile("" : "+v"(tbias[nb]));
 #pragma unroll
         for (int k = 0; k < KT; ++k) asm volatile("" : "+v"(tw[nb][k]));
+    }
+    if constexpr (NF > 0) {
+        asm volatile("" : "+v"(tb2));
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int k = 0; k < KT2; ++k) asm volatile("" : "+v"(tw2[a2][k]));
     }
     __syncthreads();
 
@@ -563,6 +588,42 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
         lds_barrier();
         FZ_STAMP(4);
         store_interior<F, G, RG2, TH, 0, TW, TH, NT>(t2, p.y1, cb, cy0, cx0, p.H, p.W, tid);
+        if constexpr (NF > 0) {
+            // next block's Conv2DTranspose (components.py:161) of the finished tile: out[2i + a][2j + e][co] = bias[co] +
+            // sum_c t2[i][j][c] W[a][e][co][c].  Per M-tile (16 pixels of one row) and a the 16 x 2 x NF results are one contiguous
+            // run of output row 2i + a: they go through a per-wave slice of t1 (free since conv1) and leave as float4.
+            static_assert(G == 1 && T1::N >= (NT / 64) * 32 * NF, "riding tconv scratch");
+            float* scr = t1 + wave * (32 * NF);
+            const int n = lane & 15, q = lane >> 4;
+#pragma unroll 1
+            for (int mt = wave; mt < TH * MPR; mt += NW) {
+                const int ty = mt / MPR, mx = mt - ty * MPR;
+                const float* ap = t2 + T2::LEAD + ty * T2::LS + (mx * 16 + n) * F + q;
+                f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int k = 0; k < KT2; ++k) {
+                    const float av = ap[4 * k];
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) acc2[a2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tw2[a2][k], acc2[a2], 0, 0, 0);
+                }
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2) {
+                    if (n < 2 * NF) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) scr[(4 * q + r) * 2 * NF + n] = acc2[a2][r] + tb2;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 8 * NF) {
+                        const float4 v = reinterpret_cast<const float4*>(scr)[lane];
+                        const size_t row = (size_t)cb * (2 * p.H) + 2 * (cy0 + ty) + a2;
+                        reinterpret_cast<float4*>(p.nup + (row * (2 * p.W) + 2 * (cx0 + mx * 16)) * NF)[lane] = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
         if (!more) break;
         // t2 shares its floats with tup; what it leaves in the padding pixels is finite (activations), which is all the junk
         // groups and the K-padding of the A operand need
@@ -670,7 +731,8 @@ bool fused_down_fwd(Model* m, int B, size_t oi, bool store_mid, const float* lab
 }
 
 // ops[oi .. oi+2] = Conv2DTranspose(CIN -> F, 2x2/2), conv3x3([up | skip] -> F), conv3x3(F -> F) of one Upsample block without BatchNorm?
-bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid) {
+bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid, int* consumed) {
+    if (consumed) *consumed = 3;
     if (!fz_enabled() || (m->desc.flags & 1) || m->desc.dtype != DNNCA_F32) return false;
     if (oi + 2 >= m->ops.size()) return false;
     Op &tc = m->ops[oi], &c0 = m->ops[oi + 1], &c1 = m->ops[oi + 2];
@@ -697,8 +759,26 @@ bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid) {
     a.y1 = c1.out.d.p;
     a.B = B; a.H = H; a.W = W;
     a.alpha0 = c0.alpha; a.alpha1 = c1.alpha;
-    const double bytes = 4.0 * B * H * W * (0.25 * CIN + F + 2 * F + F + F + F);        // tconv (in + out) + conv0 (2 in + out) + conv1 (in + out)
-    const double flops = 2.0 * B * H * W * (F * CIN + 9.0 * (2 * F * F + F * F));
+    double bytes = 4.0 * B * H * W * (0.25 * CIN + F + 2 * F + F + F + F);        // tconv (in + out) + conv0 (2 in + out) + conv1 (in + out)
+    double flops = 2.0 * B * H * W * (F * CIN + 9.0 * (2 * F * F + F * F));
+    // the next block's Conv2DTranspose(12 -> 6) rides in the epilogue (its input is c1's output tile, still in LDS)
+    if (!getenv("DNNCA_NO_TCONV_RIDE") && consumed && CIN == 12 && F == 12 && W % 32 == 0 && H % 8 == 0 && oi + 3 < m->ops.size()) {
+        Op& nt2 = m->ops[oi + 3];
+        if (nt2.type == OP_TCONV && nt2.k == 2 && nt2.inA.d.p == c1.out.d.p && nt2.inA.d.C == 12 && nt2.out.d.C == 6 && dense(nt2.inA.d) &&
+            dense(nt2.out.d) && nt2.out.d.H == 2 * H && nt2.out.d.W == 2 * W) {
+            a.nwt = m->p + nt2.w_off; a.nbt = m->p + nt2.b_off; a.nup = nt2.out.d.p;
+            a.tiles_x = W / 32; a.tiles_y = H / 8;
+            bytes += 4.0 * B * H * W * (F + 4 * 6);
+            flops += 2.0 * B * H * W * 4 * 6 * F;
+            const int ntiles = a.tiles_x * a.tiles_y * B;
+            static const int fit = fz_resident(fz::k_fz_up<12, 12, 32, 8, 512, 2, 6>, 512);
+            const int g = ntiles < fit ? ntiles : fit;
+            LAUNCH(m, "fz_up_tc_12_12", bytes, flops,
+                   hipLaunchKernelGGL((fz::k_fz_up<12, 12, 32, 8, 512, 2, 6>), dim3(g), dim3(512), 0, m->stream, a));
+            *consumed = 4;
+            return true;
+        }
+    }
 #define X(cin, f, tw, th, nt, mw)                                                                                       \
     if (CIN == cin && F == f && W % tw == 0 && H % th == 0) {                                                     \
         a.tiles_x = W / tw; a.tiles_y = H / th;                                                                   \

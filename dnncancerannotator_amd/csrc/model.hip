@@ -484,8 +484,9 @@ int Model::forward(const float* x_dev, int B, bool training) {
             case OP_TCONV: {
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
                 double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
-                if (!generic && fused_up_fwd(this, B, oi, training)) {        // tconv, conv, conv of one decoder block in one launch
-                    oi += 2;
+                int used = 3;
+                if (!generic && fused_up_fwd(this, B, oi, training, &used)) { // tconv, conv, conv of one decoder block in one launch
+                    oi += used - 1;                                           // (+ the next block's tconv when it rides along)
                     break;
                 }
                 if (!generic && fast_up3_fwd(this, B, oi)) {                  // tconv + two-source conv of the 3-channel level

@@ -500,10 +500,12 @@ def test_strip_kernels_match_the_per_layer_kernels(gpu, monkeypatch, B, H, W):
         return out.loss, g, prob, plan
 
     l1, g1, p1, plan1 = run()
-    for k in ('DNNCA_NO_TAIL3', 'DNNCA_NO_FIRST3', 'DNNCA_NO_FIRST3F', 'DNNCA_NO_UP3F', 'DNNCA_NO_TCF', 'DNNCA_NO_FOLD_ADAM', 'DNNCA_NO_PREP_RIDE'):
+    for k in ('DNNCA_NO_TAIL3', 'DNNCA_NO_FIRST3', 'DNNCA_NO_FIRST3F', 'DNNCA_NO_UP3F', 'DNNCA_NO_TCF', 'DNNCA_NO_FOLD_ADAM', 'DNNCA_NO_PREP_RIDE',
+              'DNNCA_NO_TCONV_RIDE'):
         monkeypatch.setenv(k, '1')
     l0, g0, p0, plan0 = run()
-    assert {'tail3_3x1_3', 'first3_fwd', 'up3_fwd'} <= plan1 and not ({'tail3_3x1_3', 'first3_fwd', 'up3_fwd', 'first3_bwd'} & plan0), (plan1, plan0)
+    fused = {'tail3_3x1_3', 'first3_fwd', 'up3_fwd'} | ({'fz_up_tc_12_12'} if W % 128 == 0 and H % 32 == 0 else set())
+    assert fused <= plan1 and not ((fused | {'first3_bwd'}) & plan0), (plan1, plan0)
     assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
     assert np.abs(np.asarray(p1) - np.asarray(p0)).max() <= 2e-5
     # two float32 paths sum the convolutions in different orders: a pooling window whose two largest values agree to the last bit or
