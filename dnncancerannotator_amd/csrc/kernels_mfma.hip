@@ -481,10 +481,18 @@ __device__ __forceinline__ int slab_index(int mrow, int n);
 // data-gradient MFMAs for the whole tile, waves [NW/2, NW) walk down pixel columns of the same staged tiles with a sliding
 // 3 x 3 x C window in registers and keep dW[dy][kx][ci][co] + db[co] in 84 accumulators per lane.  Every SIMD hosts one wave of
 // each kind (waves are dealt to SIMDs cyclically), so the two pipes run side by side.
-template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB, bool VW = false, bool PF = false, bool TCF = false>
+//
+// TCM (two-source 6- / 12-channel convs whose first source is the output of a 12 -> C transposed conv): as TCF, on the matrix cores.
+// The data gradient of the first source goes to an LDS tile instead of HBM; behind one more barrier the block runs
+//   T1  din[i][j][ci] = sum_(a,e,co) dup[2i+a][2j+e][co] W[a][e][co][ci]     M = 16 input pixels of a row, K = (a, e, co), N = ci
+//   T2  dW[(a,e,co)][ci] += sum_pixels dup[..](a,e,co) * in[i][j][ci]         M = (a, e, co), N = ci (+ an all-ones column: the bias
+//       gradient), K = the tile's input pixels, split over the waves; the accumulators live across tiles and leave through the
+//       transposed conv's slabs in the D layout k_pg_fold expects (kind 1) -- the layout k_tconv_bwd leaves there.
+template <int C, int NSRC, int CO, bool DGRAD, int NT, bool DB, bool VW = false, bool PF = false, bool TCF = false, bool TCM = false>
 __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs p) {
     constexpr int NW = NT / 64;
     static_assert(!TCF || (VW && NSRC == 2 && C == 3 && CO == 3), "TCF rides in the two-source 3-channel VW kernel");
+    static_assert(!TCM || (!VW && !PF && !DB && !TCF && NSRC == 2 && DGRAD && C == CO && (C == 6 || C == 12)), "TCM: two-source C -> C conv");
     static_assert(!PF || (NSRC == 1 && C == CO && DGRAD && !VW && !DB), "PF: single-source C -> C conv with data gradient");
     static_assert(!VW || (C == 3 && CO == 3 && NT == 512 && DGRAD), "VW: 3 -> 3 channels, eight waves, with data gradient");
     constexpr int NWD = VW ? NW / 2 : NW;          // waves that run the data gradient
@@ -502,7 +510,19 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
     constexpr int PFLS = (PFLEAD + PFW * CO + 3) / 4 * 4, PFN4 = PF ? PFR * PFLS / 4 : 0, PFLI = PFLS / 4, PFNI = PF ? PFR * PFLI : 0;
     // TCF: gradient of the transposed conv's output for the whole tile [TH rows][4 column blocks][32 pixels x 3] + its kernel (72)
     constexpr int TCF4 = TCF ? TH * 4 * 24 + 18 : 0;
-    __shared__ float4 lds4[MAIN4 + NW * 48 + 1 + PFN4 + (PFNI + 3) / 4 + TCF4];       // staged tiles (reused for the final reduction) + output rows + constants
+    // TCM: transposed conv 12 -> C: K = (a, e, co) in runs of KA per output-row parity a; the tile's gradient [TH][TW * C] and the
+    // transposed conv's input tile [TH/2 * TW/2 pixels][12]
+    constexpr int CIt = 12, KA = 2 * C, KTt = 4 * C, KS1 = KA / 4, MBt = (KTt + 15) / 16;
+    constexpr int LWt = Wc::TW / 2, NLP = (TH / 2) * LWt, ROWF = Wc::TW * C;
+    constexpr int DT4 = TCM ? TH * ROWF / 4 : 0, XLT4 = TCM ? NLP * CIt / 4 : 0, TCW4 = TCM ? KTt * CIt / 4 : 0;
+    static_assert(!TCM || (XLT4 <= NT && LWt % 16 == 0), "TCM: one staging slot per thread, whole M-tiles per input row");
+    constexpr int TCM0 = MAIN4 + NW * 48 + 1 + PFN4 + (PFNI + 3) / 4 + TCF4;       // float4 index of the TCM tiles
+    constexpr int DTF = TCM0 * 4, XLTF = DTF + DT4 * 4, TCWF = XLTF + XLT4 * 4;     // their float indices (+ the transposed conv's kernel)
+    // 12 channels: the kernel sits at the register limit of two waves per SIMD -- T2's sums then live in a per-wave LDS area
+    // ([wave][M block][lane] float4) instead of accumulator registers that would be live across the whole tile loop
+    constexpr bool TLDS = TCM && C == 12;
+    constexpr int TSUM0 = TCM0 + DT4 + XLT4 + TCW4, TSUM4 = TLDS ? NW * MBt * 64 : 0;
+    __shared__ float4 lds4[TSUM0 + TSUM4];       // staged tiles (reused for the final reduction) + output rows + constants
     float* orow = reinterpret_cast<float*>(lds4 + MAIN4) + (threadIdx.x >> 6) * 192;
     float4* dta4 = lds4 + MAIN4 + NW * 48 + 1 + PFN4 + (PFNI + 3) / 4;
     float* tcw = reinterpret_cast<float*>(dta4 + TH * 4 * 24);
@@ -557,6 +577,19 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
 #pragma unroll
     for (int i = 0; i < NWACC; ++i) wacc[i] = 0.f;
 
+    // TCM operands: T1's B operand is the transposed conv's kernel in LDS (row k = 4 s + q); T2's accumulators and LDS addressing
+    f32x4 tacc2[TCM ? MBt : 1];
+    if constexpr (TCM) {
+        if (tid < TCW4) lds4[TCM0 + DT4 + XLT4 + tid] = reinterpret_cast<const float4*>(p.tc_w)[tid];
+        if constexpr (TLDS) {
+#pragma unroll
+            for (int t = 0; t < MBt; ++t) lds4[TSUM0 + (wave * MBt + t) * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < MBt; ++t) {
+            tacc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     if (VW && wave < NWD) __builtin_amdgcn_s_setprio(2);     // the MFMA waves' few vector instructions go first; the FMA waves fill in
     float breg[DGRAD ? NPASS * KSd : 1];
     if (DGRAD) {
@@ -699,6 +732,14 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
                 for (int ci = 0; ci < 6; ++ci) tin[ci] = ip[ci];
             }
         }
+        // TCM: this thread's float4 of the transposed conv's input tile (ahead of the prefetch, as tin)
+        float4 txl = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (TCM) {
+            if (tid < XLT4) {
+                const int r = tid / (LWt * 3), c = tid - r * (LWt * 3);
+                txl = reinterpret_cast<const float4*>(p.tc_in)[(((size_t)b * (p.H >> 1) + (y0 >> 1) + r) * (p.W >> 1) + (x0 >> 1)) * 3 + c];
+            }
+        }
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             int nb, nx0, ny0;
@@ -767,6 +808,8 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
                         if (TCF && sp == 0) {
                             // the first source's gradient (= the transposed conv's output gradient) stays in LDS (whole tiles only)
                             if (lane < PER4) dta4[(ty * 4 + tx) * 24 + i4] = reinterpret_cast<const float4*>(orow)[lane];
+                        } else if (TCM && src == 0) {
+                            if (lane < PER4) lds4[TCM0 + (ty * Wc::MTX + tx) * PER4 + i4] = reinterpret_cast<const float4*>(orow)[lane];
                         } else if (lane < SPL * PER4 && f0 < p.W * C && y < p.H) {
                             float4 v = reinterpret_cast<const float4*>(orow)[lane];
                             float* dst = dxs + ((size_t)b * p.H + y) * p.W * C + f0;
@@ -786,6 +829,74 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
+                }
+            }
+        }
+        if constexpr (TCM) {
+            static_assert(Wc::MTX * (16 * Gd * C / 4) == ROWF / 4, "TCM: the M-tiles of a row tile the gradient row");
+            if (tid < XLT4) lds4[TCM0 + DT4 + tid] = txl;
+            lds_barrier();                                    // the tile's first-source gradient and the input tile are complete
+            // LDS addressing of T1 / T2, recomputed per tile from an opaque copy of the lane id: as loop invariants these seven
+            // values would be live across the whole tile loop of a kernel that sits at its register limit
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int m16 = lo & 15, q = lo >> 4;
+            int offT[MBt];
+#pragma unroll
+            for (int t = 0; t < MBt; ++t) {
+                const int k = 16 * t + m16, a = k / KA, kr = k - a * KA;
+                offT[t] = k < KTt ? DTF + a * ROWF + 2 * q * C + kr : CST0;
+            }
+            const int boffT = m16 < CIt ? XLTF + q * CIt + m16 : (m16 == CIt ? CST1 : CST0), bstepT = m16 < CIt ? 4 * CIt : 0;
+            const int woffT = m16 < CIt ? TCWF + q * CIt + m16 : CST0, wstepT = bstepT;
+            // ---- T1: the transposed conv's data gradient, one M-tile = 16 input pixels of a row
+#pragma unroll 1
+            for (int mt = wave; mt < NLP / 16; mt += NW) {
+                const int li = mt / (LWt / 16), mx = mt - li * (LWt / 16);
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int kk = 0; kk < KS1; ++kk)
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(ldsf[DTF + (2 * li + a) * ROWF + 2 * (mx * 16 + m16) * C + 4 * kk + q],
+                                                                 ldsf[woffT + (a * KS1 + kk) * wstepT], d, 0, 0, 0);
+                if (m16 < CIt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) orow[(4 * q + r) * CIt + m16] = d[r];
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 16 * CIt / 4) {
+                    float4 v = reinterpret_cast<const float4*>(orow)[lane];
+                    if (p.tc_mask) {
+                        const float4 xv = lds4[TCM0 + DT4 + (li * LWt + mx * 16) * 3 + lane];
+                        v.x *= xv.x > 0.f ? 1.0f : p.tc_alpha;
+                        v.y *= xv.y > 0.f ? 1.0f : p.tc_alpha;
+                        v.z *= xv.z > 0.f ? 1.0f : p.tc_alpha;
+                        v.w *= xv.w > 0.f ? 1.0f : p.tc_alpha;
+                    }
+                    reinterpret_cast<float4*>(p.tc_din)[(((size_t)b * (p.H >> 1) + (y0 >> 1) + li) * (p.W >> 1) + (x0 >> 1) + mx * 16) * 3 + lane] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- T2: the transposed conv's weight (+ bias) gradient, K-steps of 4 input pixels dealt to the waves
+            if constexpr (TLDS) {
+#pragma unroll
+                for (int t = 0; t < MBt; ++t) tacc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll 1
+            for (int st = wave; st < NLP / 4; st += NW) {
+                const int sd = ((4 * st) / LWt) * 2 * ROWF + ((4 * st) % LWt) * 2 * C;
+                const float bv = ldsf[boffT + st * bstepT];
+#pragma unroll
+                for (int t = 0; t < MBt; ++t)
+                    tacc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ldsf[offT[t] + (16 * (t + 1) <= KTt || offT[t] != CST0 ? sd : 0)], bv, tacc2[t], 0, 0, 0);
+            }
+            if constexpr (TLDS) {
+#pragma unroll
+                for (int t = 0; t < MBt; ++t) {
+                    float4 v = lds4[TSUM0 + (wave * MBt + t) * 64 + lane];
+                    v.x += tacc2[t][0]; v.y += tacc2[t][1]; v.z += tacc2[t][2]; v.w += tacc2[t][3];
+                    lds4[TSUM0 + (wave * MBt + t) * 64 + lane] = v;
                 }
             }
         }
@@ -1028,6 +1139,26 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         const float v = (red[i] + red[PER + i]) + (red[2 * PER + i] + red[3 * PER + i]);
         const int s = i / (MT * 256), e = i - s * (MT * 256);
         atomicAdd(p.slabs[s] + (size_t)bucket * (MT * 256) + e, v);
+    }
+    if constexpr (TCM) {
+        static_assert(NW * MBt * 256 <= 4 * PER, "TCM: the waves' partial sums fit the reduction area");
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MBt; ++t) {
+            if constexpr (TLDS) {
+                const float4 v = lds4[TSUM0 + (wave * MBt + t) * 64 + lane];
+                tacc2[t] = f32x4{v.x, v.y, v.z, v.w};
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * (MBt * 256) + (t * 4 + r) * 64 + lane] = tacc2[t][r];
+        }
+        __syncthreads();
+        for (int i = tid; i < MBt * 256; i += NT) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[w * (MBt * 256) + i];
+            atomicAdd(p.tc_slabs + (size_t)bucket * (MBt * 256) + i, v);
+        }
     }
     STAMP_END(7);
 }
@@ -1962,6 +2093,33 @@ bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, do
                    hipLaunchKernelGGL((k_pgbwd<3, 2, 3, true, 512, false, true>), dim3(g), dim3(512), 0, m->stream, a));
         }
         return true;
+    }
+    // 6 / 12 channels, two sources, the first one the output of a 12 -> C transposed conv: that layer's backward rides along (TCM)
+    if (o.need_din && NS == 2 && C == CO && (C == 6 || C == 12) && !getenv("DNNCA_NO_TCM")) {
+        const size_t oi = (size_t)(&o - m->ops.data());
+        Op* tc = oi >= 1 && oi < m->ops.size() ? &m->ops[oi - 1] : nullptr;
+        auto tw = tc ? pl.wslot.find({tc, 0}) : pl.wslot.end();
+        const int TWc = 32 * (12 / CO);
+        if (tc && tc->type == OP_TCONV && tc->k == 2 && tc->inA.d.C == 12 && tc->out.d.C == C && tc->out.d.p == o.inA.d.p &&
+            tw != pl.wslot.end() && fast_tconv_supported(m, *tc) && !tc->accA && !o.accA && !o.maskA && dense(tc->inA.d) && dense(tc->inA.g) &&
+            dense(o.inA.d) && tc->inA.d.H * 2 == a.H && tc->inA.d.W * 2 == a.W && a.W % TWc == 0 && a.H % TH == 0) {
+            a.tc_in = tc->inA.d.p; a.tc_din = tc->inA.g.p; a.tc_w = m->p + tc->w_off;
+            a.tc_slabs = pl.slabs + pl.folds[tw->second].slab_off;
+            a.tc_mask = tc->maskA; a.tc_alpha = tc->mask_alpha;
+            const double tb = 4.0 * ((double)B * a.H * a.W * C + (double)B * (a.H / 2) * (a.W / 2) * 12);      // the transposed conv's out + in
+            const double tfl = 4.0 * B * a.H * a.W * C * 12;
+#define TCMX(c)                                                                                                         \
+            if (C == c) {                                                                                               \
+                static const int fit = resident_blocks(k_pgbwd<c, 2, c, true, 512, false, false, false, false, true>, 1 << 20); \
+                const int g = pl.nblocks_forced ? nb : (ntiles < fit ? ntiles : fit);                                   \
+                LAUNCH(m, "pgbwd_tc_" #c "x2_" #c, bytes + 2 * tb, fl + tfl,                                            \
+                       hipLaunchKernelGGL((k_pgbwd<c, 2, c, true, 512, false, false, false, false, true>), dim3(g), dim3(512), 0, m->stream, a)); \
+                m->tconv_done = tc;                                                                                     \
+                return true;                                                                                            \
+            }
+            TCMX(6) TCMX(12)
+#undef TCMX
+        }
     }
 #define X(c, ns, co)                                                                                            \
     if (C == c && NS == ns && CO == co) {                                                                       \

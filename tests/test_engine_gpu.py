@@ -441,14 +441,17 @@ def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
 
 
 @pytest.mark.parametrize('B, H, W, strip', [(2, 40, 128, True), (8, 16, 256, True), (2, 40, 128, False), (8, 16, 256, False),
-                                            (3, 24, 200, True), (1, 72, 64, True)])
+                                            (3, 24, 200, True), (1, 72, 64, True), (2, 64, 256, True)])
 def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypatch, B, H, W, strip):
     """configs/unet.yaml, the vector-ALU kernels of the full-resolution 3-channel level against the float64 oracle, every variable on
     its own scale.  strip: the column-strip kernels (strip_dev.h; strips of 60 columns, row chunks; shapes with partial strips, one
     strip, chunk counts not divisible by 8) -- k_tail3: the conv that feeds the head runs forward + head + loss + its whole backward
     in one launch; k_first3: the backward of the first encoder block (second conv with the folded max-pool backward + the first
     conv's weight gradient) in one launch.  Without them and on images made of whole 128 x 8 tiles those convs' backward is the
-    tile kernel k_bwd3v (plain / with the pool fold); the (8, 16, 256) shape has a tile count divisible by 8 (XCD-aware order)."""
+    tile kernel k_bwd3v (plain / with the pool fold); the (8, 16, 256) shape has a tile count divisible by 8 (XCD-aware order).
+    (2, 64, 256) is made of whole tiles at every level: there the transposed convs' backward rides in the launch of the two-source
+    conv behind them on all three levels (k_pgbwd TCF / TCM) and the 12 -> 6 transposed conv's forward in the fused 12-channel
+    decoder block (k_fz_up)."""
     if not strip:
         monkeypatch.setenv('DNNCA_NO_TAIL3', '1')
         monkeypatch.setenv('DNNCA_NO_FIRST3', '1')
@@ -469,13 +472,15 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
     floor = [10 * np.abs(g32[sl] - gref[sl]).max() for _, sl in Hp.tensor_slices(spec)]
     Hp.assert_grads_per_tensor(spec, m.get_grads(), gref, 2e-5, floor=floor)
     plan = set(r[0] for r in m.plan())
+    if (B, H, W) == (2, 64, 256):
+        assert {'pgbwd_tc_3x2_3', 'pgbwd_tc_6x2_6', 'pgbwd_tc_12x2_12', 'fz_up_tc_12_12'} <= plan and not any(k.startswith('tconv') for k in plan), plan
     assert ('tail3_3x1_3' if strip else 'bwd3v_3x1_3') in plan, plan
     if 'fz_down_1_3' in plan or 'first3_fwd' in plan:          # the fused first block records the pool's window positions
         assert ('first3_bwd' if strip else 'bwd3v_pool_3x1_3') in plan and 'pgbwd_w_1x1_3' not in plan or not strip, plan
     m.close()
 
 
-@pytest.mark.parametrize('B, H, W', [(1, 8, 64), (2, 24, 120), (5, 32, 248), (3, 88, 504), (1, 512, 512), (11, 64, 64)])
+@pytest.mark.parametrize('B, H, W', [(1, 8, 64), (2, 24, 120), (5, 32, 248), (3, 88, 504), (1, 512, 512), (11, 64, 64), (3, 96, 384)])
 def test_strip_kernels_match_the_per_layer_kernels(gpu, monkeypatch, B, H, W):
     """The column-strip kernels (k_tail3, k_first3, k_first3_fwd, k_up3_fwd) and the ride-along launches (transposed-conv backward in
     the two-source conv's launch, Adam in the slab fold, operand preparation in the first strip launch) against the per-layer / tile
@@ -501,10 +506,10 @@ def test_strip_kernels_match_the_per_layer_kernels(gpu, monkeypatch, B, H, W):
 
     l1, g1, p1, plan1 = run()
     for k in ('DNNCA_NO_TAIL3', 'DNNCA_NO_FIRST3', 'DNNCA_NO_FIRST3F', 'DNNCA_NO_UP3F', 'DNNCA_NO_TCF', 'DNNCA_NO_FOLD_ADAM', 'DNNCA_NO_PREP_RIDE',
-              'DNNCA_NO_TCONV_RIDE'):
+              'DNNCA_NO_TCONV_RIDE', 'DNNCA_NO_TCM'):
         monkeypatch.setenv(k, '1')
     l0, g0, p0, plan0 = run()
-    fused = {'tail3_3x1_3', 'first3_fwd', 'up3_fwd'} | ({'fz_up_tc_12_12'} if W % 128 == 0 and H % 32 == 0 else set())
+    fused = {'tail3_3x1_3', 'first3_fwd', 'up3_fwd'} | ({'fz_up_tc_12_12', 'pgbwd_tc_6x2_6', 'pgbwd_tc_12x2_12'} if W % 128 == 0 and H % 32 == 0 else set())
     assert fused <= plan1 and not ((fused | {'first3_bwd'}) & plan0), (plan1, plan0)
     assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
     assert np.abs(np.asarray(p1) - np.asarray(p0)).max() <= 2e-5
