@@ -1697,9 +1697,11 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
 // 144 accumulator registers per wave, so two waves fit a SIMD: full-rate MFMA issue (one wave alone reaches 1.7 of 2.46
 // PFLOP/s) and one wave's transposing reads hide behind the other's MFMAs.  Every wave still adds distinct elements to the
 // gradient: the atomic traffic is unchanged.
-__global__ __launch_bounds__(512, 2) void k_igb_wgrad64w(ig::WgArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16_t ximg[PATCH * WRS];
-    __shared__ __attribute__((aligned(16))) bf16_t gimg[TY * TX * WRS];
+// Two LDS buffers: the next tile (in registers since the previous iteration) is written into the other buffer while this one is
+// consumed -- one barrier per tile and no wave waits for the commit.
+__global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t ximg2[2][PATCH * WRS];
+    __shared__ __attribute__((aligned(16))) bf16_t gimg2[2][TY * TX * WRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
     const int m16 = lane & 15, q = lane >> 4;
     const int gq = (lane >> 2) & 3, gp = lane & 3;
@@ -1746,7 +1748,9 @@ __global__ __launch_bounds__(512, 2) void k_igb_wgrad64w(ig::WgArgs p) {
                 gr[u] = *reinterpret_cast<const bf16x4*>(g16 + (((size_t)b * p.H + iy) * p.W + ix) * p.cout + blockIdx.z * 64 + 4 * n4);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        bf16_t* ximg = ximg2[buf];
+        bf16_t* gimg = gimg2[buf];
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const int i = tid + 512 * u, px = i >> 4, c4 = i & 15;
@@ -1759,16 +1763,23 @@ __global__ __launch_bounds__(512, 2) void k_igb_wgrad64w(ig::WgArgs p) {
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) issue(tile);
+    int tile = blockIdx.x, buf = 0;
+    if (tile < ntiles) {
+        issue(tile);
+        commit(0);
+        if (tile + p.psplit < ntiles) issue(tile + p.psplit);
+    }
+    lds_barrier();
     const int xbase = (4 * q + gq) * WRS + 16 * wm + 4 * gp;
     const int gbase = (4 * q + gq) * WRS + 32 * wn + 4 * gp;
 #pragma unroll 1
     for (; tile < ntiles; tile += p.psplit) {
-        lds_barrier();              // the previous tile's fragment reads are complete
-        commit();
-        if (tile + p.psplit < ntiles) issue(tile + p.psplit);
-        lds_barrier();
+        if (tile + p.psplit < ntiles) {
+            commit(buf ^ 1);            // every wave has left the previous tile (the barrier below): its buffer is free
+            if (tile + 2 * p.psplit < ntiles) issue(tile + 2 * p.psplit);
+        }
+        const bf16_t* ximg = ximg2[buf];
+        const bf16_t* gimg = gimg2[buf];
 #pragma unroll 1
         for (int s = 0; s < TY / 2; ++s) {
             bf16x8 bv[2];
@@ -1788,6 +1799,8 @@ __global__ __launch_bounds__(512, 2) void k_igb_wgrad64w(ig::WgArgs p) {
                 for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bv[j], accb[j], 0, 0, 0);
             }
         }
+        lds_barrier();
+        buf ^= 1;
     }
     // D[ci = 16 wm + 4q + i][co = 32 wn + 16j + m16]
 #pragma unroll
