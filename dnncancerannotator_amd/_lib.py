@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libdnnca.so')
+LIB_PATH = os.environ.get('DNNCA_LIB') or os.path.join(HERE, 'libdnnca.so')      # DNNCA_LIB: A/B of two builds (development aid)
 
 OK = 0
 ARCH_UNET, ARCH_MULMO = 0, 1

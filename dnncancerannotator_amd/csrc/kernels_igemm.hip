@@ -1726,26 +1726,44 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
     const bf16_t* x16 = reinterpret_cast<const bf16_t*>(p.x);
     const bf16_t* g16 = reinterpret_cast<const bf16_t*>(p.dz);
     const bf16x4 zero4 = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    // Buffer loads with 32-bit byte offsets: what depends on the thread (patch pixel, channel quad) is computed once, a tile adds
+    // one wave-uniform base; pixels outside the image get an out-of-range offset and come back as zeros (the staging of a
+    // tile was ~150 vector instructions per wave with 64-bit address arithmetic: a fifth of the kernel).
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(npix * p.cs * 2), BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (unsigned)(npix * p.cout * 2), BUF_FLAGS);
+    int xyl[XU], xoff[XU], gyl[GU], goff[GU];          // (ly << 16 | lx) and the thread's byte offset inside a tile at (0, 0)
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        const int i = tid + 512 * u, px = i >> 4, c4 = i & 15;
+        const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
+        xyl[u] = px < PATCH ? (ly << 16) | lx : 0x7fff7fff;              // past the patch: never inside
+        xoff[u] = ((ly * p.W + lx) * p.cs + c0 + 4 * c4) * 2;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+        const int i = tid + 512 * u, px = i >> 4, n4 = i & 15;
+        const int ly = px / TX, lx = px - ly * TX;
+        gyl[u] = (ly << 16) | lx;
+        goff[u] = ((ly * p.W + lx) * p.cout + (int)blockIdx.z * 64 + 4 * n4) * 2;
+    }
     auto issue = [&](int tile) {
         const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x, b = d_ty.div(trow), by = trow - b * p.tiles_y;
         const int x0 = bx * TX, y0 = by * TY;
+        const int xb = (((b * p.H + y0 - 1) * p.W + x0 - 1) * p.cs) * 2, gb = (((b * p.H + y0) * p.W + x0) * p.cout) * 2;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int i = tid + 512 * u, px = i >> 4, c4 = i & 15;
-            const int ly = px / (TX + 2), lx = px - ly * (TX + 2);
-            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
-            xr[u] = zero4;
-            if (px < PATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                xr[u] = *reinterpret_cast<const bf16x4*>(x16 + (((size_t)b * p.H + iy) * p.W + ix) * p.cs + c0 + 4 * c4);
+            const int iy = y0 - 1 + (xyl[u] >> 16), ix = x0 - 1 + (xyl[u] & 0xffff);
+            const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = in ? (unsigned)(xb + xoff[u]) : 0x80000000u;
+            xr[u] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rsx, off, 0, 0));
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int i = tid + 512 * u, px = i >> 4, n4 = i & 15;
-            const int ly = px / TX, lx = px - ly * TX;
-            const int iy = y0 + ly, ix = x0 + lx;
-            gr[u] = zero4;
-            if (iy < p.H && ix < p.W)
-                gr[u] = *reinterpret_cast<const bf16x4*>(g16 + (((size_t)b * p.H + iy) * p.W + ix) * p.cout + blockIdx.z * 64 + 4 * n4);
+            const int iy = y0 + (gyl[u] >> 16), ix = x0 + (gyl[u] & 0xffff);
+            const bool in = iy < p.H && ix < p.W;
+            const unsigned off = in ? (unsigned)(gb + goff[u]) : 0x80000000u;
+            gr[u] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rsg, off, 0, 0));
         }
     };
     auto commit = [&](int buf) {
@@ -2407,7 +2425,9 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         if (!pl.wg_slabs && !m->dry && m->alloc((void**)&pl.wg_slabs, (size_t)WG_BUCKETS * WG_SLAB_FLOATS * 4) != DNNCA_OK) pl.wg_slabs = nullptr;
         bucketed = m->dry || pl.wg_slabs != nullptr;          // the dry run lists the launches of the real one
     }
-    // weight (+bias) gradient, one launch per source
+    // weight (+bias) gradient, one launch per source -- on the side stream where the step allows (Model::wg_stream)
+    hipStream_t main_stream = m->stream;
+    const bool side = m->wg_side_begin();
     for (int s = 0; s < (CB ? 2 : 1); ++s) {
         ig::WgArgs w{};
         w.x = s == 0 ? o.inA.d.p : o.inB.d.p;
@@ -2439,7 +2459,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             const dim3 g64(w.psplit, w.cs / 64, CO / 64);
             const bool xh = (s == 0 ? o.inA.d.h : o.inB.d.h) != 0, gh = o.out.g.h != 0;
             static const int narrow = getenv("DNNCA_WGRAD64_NARROW") != nullptr;          // tuning aid
-            if (xh && gh && !narrow) {         // eight waves per block (bf16-stored operands)
+            if (xh && gh && !narrow && (double)B * w.H * w.W * (w.cs > CO ? w.cs : CO) * 2.0 < 2.0e9) {         // eight waves per block (bf16-stored operands, 32-bit byte offsets)
                 LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL(igb::k_igb_wgrad64w, g64, dim3(512), 0, m->stream, w));
                 continue;
             }
@@ -2475,6 +2495,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         LAUNCH(m, "wg_fold", 4.0 * WG_BUCKETS * (n_w + CO), 0,
                hipLaunchKernelGGL(ig::k_wg_fold, dim3((n_w + CO + 255) / 256), dim3(256), 0, m->stream, pl.wg_slabs, WG_BUCKETS,
                                   WG_SLAB_FLOATS, n_w, m->g + o.w_off, m->g + o.b_off, CO));
+    if (side) m->wg_side_end(main_stream);
     if (o.need_din) {
         ig::ConvArgs a{};
         a.src[0] = o.out.g.p; a.c_src0 = CO; a.c_src1 = 0;
@@ -2563,8 +2584,11 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
         const dim3 gw(a.psplit, a.cout / 64, a.cin / 64), gd((a.npix + 127) / 128, a.cin / 64);
         const bool xh = o.inA.d.h != 0, gh = o.out.g.h != 0;
 #define TW64(XH, GH) LAUNCH(m, "igb_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((igb::k_igb_tconv_wgrad64<XH, GH>), gw, dim3(256), 0, m->stream, a))
+        hipStream_t main_stream = m->stream;
+        const bool side = m->wg_side_begin();          // a leaf of the backward pass: on the side stream where the step allows
         if (xh) { if (gh) TW64(true, true); else TW64(true, false); }
         else { if (gh) TW64(false, true); else TW64(false, false); }
+        if (side) m->wg_side_end(main_stream);
 #undef TW64
         if (gh)
             LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_dgrad<true>, gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
@@ -2572,6 +2596,8 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
             LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_dgrad<false>, gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
         return true;
     }
+    hipStream_t main_stream = m->stream;
+    const bool side = m->wg_side_begin();
     if ((double)a.npix * 4.0 * a.cout * 4.0 < 2.0e9 && (double)a.npix * a.cin * 4.0 < 2.0e9 && !getenv("DNNCA_TCWGRAD1")) {
         // second generation: (16 mw x 16 nn) channel tiles x 4 parities, 32-bit byte offsets
         const int mw = a.cout % 64 == 0 ? 4 : (a.cout % 32 == 0 ? 2 : 1), nn = pick_nn(a.cin);
@@ -2599,6 +2625,7 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
         else if (nn == 2) LAUNCH(m, "ig_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad<2>), grid, dim3(256), 0, m->stream, a));
         else LAUNCH(m, "ig_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad<1>), grid, dim3(256), 0, m->stream, a));
     }
+    if (side) m->wg_side_end(main_stream);
     {
         const int nn = pick_nn(a.cin);
         dim3 grid((a.npix + 127) / 128, a.cin / (16 * nn));

@@ -44,7 +44,42 @@ Model::~Model() {
     if (ev_bucket) (void)hipEventDestroy(ev_bucket);
     if (ev_comm_done) (void)hipEventDestroy(ev_comm_done);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    if (wg_fork) (void)hipEventDestroy(wg_fork);
+    if (wg_join) (void)hipEventDestroy(wg_join);
+    if (wg_stream) (void)hipStreamDestroy(wg_stream);
     if (stream) (void)hipStreamDestroy(stream);
+}
+
+bool Model::wg_side_begin() {
+    static const bool off = getenv("DNNCA_NO_WG_STREAM") != nullptr;
+    // profiles time one launch after the other; the dry run launches nothing; with a communicator the gradient buckets follow the
+    // main stream's order
+    if (off || dry || prof_mode || comm || !merged_launches()) return false;
+    if (!wg_stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo: the numerically largest = least urgent
+        const char* pe = getenv("DNNCA_WG_PRIO");                   // tuning aid: 0 normal, 1 least urgent (default), 2 most urgent
+        const int prio = !pe || atoi(pe) == 1 ? lo : (atoi(pe) == 2 ? hi : 0);
+        if (hipStreamCreateWithPriority(&wg_stream, hipStreamNonBlocking, prio) != hipSuccess) { wg_stream = nullptr; return false; }
+        if (hipEventCreateWithFlags(&wg_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&wg_join, hipEventDisableTiming) != hipSuccess)
+            return false;
+    }
+    if (!wg_fork || !wg_join) return false;
+    if (hipEventRecord(wg_fork, stream) != hipSuccess || hipStreamWaitEvent(wg_stream, wg_fork, 0) != hipSuccess) return false;
+    wg_pending = true;
+    stream = wg_stream;
+    return true;
+}
+
+void Model::wg_side_end(hipStream_t main) { stream = main; }
+
+int Model::wg_side_join() {
+    if (!wg_pending) return DNNCA_OK;
+    wg_pending = false;
+    HIP_TRY(hipEventRecord(wg_join, wg_stream));
+    HIP_TRY(hipStreamWaitEvent(stream, wg_join, 0));
+    return DNNCA_OK;
 }
 
 int Model::alloc(void** ptr, size_t bytes) {
@@ -680,6 +715,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 }
             }
         }
+        DN_TRY(wg_side_join());
         DN_TRY(fast_finish_backward(this));
         if (desc.l2 > 0.f) {
             for (auto& pi : params) {
