@@ -2426,94 +2426,103 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         bucketed = m->dry || pl.wg_slabs != nullptr;          // the dry run lists the launches of the real one
     }
     // weight (+bias) gradient, one launch per source -- on the side stream where the step allows (Model::wg_stream)
-    hipStream_t main_stream = m->stream;
-    const bool side = m->wg_side_begin();
-    for (int s = 0; s < (CB ? 2 : 1); ++s) {
-        ig::WgArgs w{};
-        w.x = s == 0 ? o.inA.d.p : o.inB.d.p;
-        w.dz = o.out.g.p;
-        w.dw = bucketed ? pl.wg_slabs : m->g + o.w_off;
-        w.dbias = s == 0 ? (bucketed ? pl.wg_slabs + n_w : m->g + o.b_off) : nullptr;
-        w.nbuckets = bucketed ? WG_BUCKETS : 1;
-        w.bucket_stride = WG_SLAB_FLOATS;
-        w.cs = s == 0 ? CA : CB;
-        w.ci_off = s == 0 ? 0 : CA;
-        w.cin_total = CA + CB;
-        w.cout = CO;
-        w.B = B; w.H = o.out.d.H; w.W = o.out.d.W;
-        w.tiles_x = tiles_x; w.tiles_y = tiles_y;
-        const int nn = pick_nn(CO);
-        const int combos = (w.cs / ig::CK) * (CO / (16 * nn));
-        const int ntiles = tiles_x * tiles_y * B;
-        int psplit = (1024 + combos - 1) / combos;
-        if (psplit > ntiles) psplit = ntiles;
-        if (psplit < 1) psplit = 1;
-        w.psplit = psplit;
-        dim3 grid(psplit, w.cs / ig::CK, CO / (16 * nn));
-        const double bb = (out_bytes + in_bytes) / (CB ? 2 : 1), ff = flops / (CB ? 2 : 1);
-        if (use_bf16(m, o) && CO % 64 == 0 && w.cs % 64 == 0) {
-            const int combos64 = (w.cs / 64) * (CO / 64);
-            int ps = (256 + combos64 - 1) / combos64;
-            if (ps > ntiles) ps = ntiles;
-            w.psplit = ps < 1 ? 1 : ps;
-            const dim3 g64(w.psplit, w.cs / 64, CO / 64);
-            const bool xh = (s == 0 ? o.inA.d.h : o.inB.d.h) != 0, gh = o.out.g.h != 0;
-            static const int narrow = getenv("DNNCA_WGRAD64_NARROW") != nullptr;          // tuning aid
-            if (xh && gh && !narrow && (double)B * w.H * w.W * (w.cs > CO ? w.cs : CO) * 2.0 < 2.0e9) {         // eight waves per block (bf16-stored operands, 32-bit byte offsets)
-                LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL(igb::k_igb_wgrad64w, g64, dim3(512), 0, m->stream, w));
-                continue;
-            }
-#define WG64(XH, GH) LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad64<XH, GH>), g64, dim3(256), 0, m->stream, w))
-            if (xh) { if (gh) WG64(true, true); else WG64(true, false); }
-            else { if (gh) WG64(false, true); else WG64(false, false); }
-#undef WG64
-        } else if (!use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (w.cs > CO ? w.cs : CO) * 4.0 < 2.0e9 &&
-                   !getenv("DNNCA_WGRAD1")) {
-            const int mw = w.cs % 64 == 0 ? 4 : (w.cs % 32 == 0 ? 2 : 1);
-            const int tm = (4 / mw) < (4 / nn) ? (4 / mw) : (4 / nn);
-            const int nt2 = tiles_x * ((o.out.d.H + 8 * tm - 1) / (8 * tm)) * B;
-            const int combos2 = (w.cs / (16 * mw)) * (CO / (16 * nn));
-            int ps = (256 + combos2 - 1) / combos2;
-            if (ps > nt2) ps = nt2;
-            w.psplit = ps < 1 ? 1 : ps;
-            dim3 g2(w.psplit, w.cs / (16 * mw), CO / (16 * nn));
-            static const int wg2_narrow = getenv("DNNCA_WGRAD2_NARROW") != nullptr;        // tuning aid
-#define WG2(MWv, NNv, NWv) LAUNCH(m, "ig_wgrad2", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad2<MWv, NNv, NWv>), g2, dim3(64 * NWv), 0, m->stream, w))
-#define WG2N(MWv) do { if (nn == 4) WG2(MWv, 4, 4); \
-                       else if (nn == 2) { if (wg2_narrow) WG2(MWv, 2, 4); else WG2(MWv, 2, 8); } \
-                       else { if (wg2_narrow) WG2(MWv, 1, 4); else WG2(MWv, 1, 8); } } while (0)
-            if (mw == 4) WG2N(4); else if (mw == 2) WG2N(2); else WG2N(1);
-#undef WG2N
-#undef WG2
-        } else if (use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
-        else if (use_bf16(m, o) && nn == 2) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<2>), grid, dim3(256), 0, m->stream, w));
-        else if (nn == 4) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<4>), grid, dim3(256), 0, m->stream, w));
-        else if (nn == 2) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<2>), grid, dim3(256), 0, m->stream, w));
-        else LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<1>), grid, dim3(256), 0, m->stream, w));
-    }
-    if (bucketed)
-        LAUNCH(m, "wg_fold", 4.0 * WG_BUCKETS * (n_w + CO), 0,
-               hipLaunchKernelGGL(ig::k_wg_fold, dim3((n_w + CO + 255) / 256), dim3(256), 0, m->stream, pl.wg_slabs, WG_BUCKETS,
-                                  WG_SLAB_FLOATS, n_w, m->g + o.w_off, m->g + o.b_off, CO));
-    if (side) m->wg_side_end(main_stream);
-    if (o.need_din) {
-        ig::ConvArgs a{};
-        a.src[0] = o.out.g.p; a.c_src0 = CO; a.c_src1 = 0;
-        a.src_half = o.out.g.h;
-        a.w = pl.flipped + o.w_off;
-        a.dst[0] = o.inA.g.p; a.dst[1] = o.inB.g.p;
-        a.n_dst0 = CA; a.n_dst1 = CB;
-        a.mask[0] = o.maskA ? o.inA.d.p : nullptr;
-        a.mask[1] = o.maskB ? o.inB.d.p : nullptr;
-        a.acc[0] = o.accA; a.acc[1] = o.accB;
-        a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
-        a.tiles_x = tiles_x; a.tiles_y = tiles_y;
-        a.alpha = o.mask_alpha;
-        if (use_bf16(m, o))
-            launch_igb<1>(m, a, pl.wd + o.w_off, CA + CB, "igb_conv_dgrad", out_bytes + in_bytes, flops);
-        else
-            launch_ig<1>(m, a, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
-    }
+    auto weight_gradient = [&]() {
+        hipStream_t main_stream = m->stream;
+        const bool side = m->wg_side_begin();
+        for (int s = 0; s < (CB ? 2 : 1); ++s) {
+            ig::WgArgs w{};
+            w.x = s == 0 ? o.inA.d.p : o.inB.d.p;
+            w.dz = o.out.g.p;
+            w.dw = bucketed ? pl.wg_slabs : m->g + o.w_off;
+            w.dbias = s == 0 ? (bucketed ? pl.wg_slabs + n_w : m->g + o.b_off) : nullptr;
+            w.nbuckets = bucketed ? WG_BUCKETS : 1;
+            w.bucket_stride = WG_SLAB_FLOATS;
+            w.cs = s == 0 ? CA : CB;
+            w.ci_off = s == 0 ? 0 : CA;
+            w.cin_total = CA + CB;
+            w.cout = CO;
+            w.B = B; w.H = o.out.d.H; w.W = o.out.d.W;
+            w.tiles_x = tiles_x; w.tiles_y = tiles_y;
+            const int nn = pick_nn(CO);
+            const int combos = (w.cs / ig::CK) * (CO / (16 * nn));
+            const int ntiles = tiles_x * tiles_y * B;
+            int psplit = (1024 + combos - 1) / combos;
+            if (psplit > ntiles) psplit = ntiles;
+            if (psplit < 1) psplit = 1;
+            w.psplit = psplit;
+            dim3 grid(psplit, w.cs / ig::CK, CO / (16 * nn));
+            const double bb = (out_bytes + in_bytes) / (CB ? 2 : 1), ff = flops / (CB ? 2 : 1);
+            if (use_bf16(m, o) && CO % 64 == 0 && w.cs % 64 == 0) {
+                const int combos64 = (w.cs / 64) * (CO / 64);
+                int ps = (256 + combos64 - 1) / combos64;
+                if (ps > ntiles) ps = ntiles;
+                w.psplit = ps < 1 ? 1 : ps;
+                const dim3 g64(w.psplit, w.cs / 64, CO / 64);
+                const bool xh = (s == 0 ? o.inA.d.h : o.inB.d.h) != 0, gh = o.out.g.h != 0;
+                static const int narrow = getenv("DNNCA_WGRAD64_NARROW") != nullptr;          // tuning aid
+                if (xh && gh && !narrow && (double)B * w.H * w.W * (w.cs > CO ? w.cs : CO) * 2.0 < 2.0e9) {         // eight waves per block (bf16-stored operands, 32-bit byte offsets)
+                    LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL(igb::k_igb_wgrad64w, g64, dim3(512), 0, m->stream, w));
+                    continue;
+                }
+    #define WG64(XH, GH) LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad64<XH, GH>), g64, dim3(256), 0, m->stream, w))
+                if (xh) { if (gh) WG64(true, true); else WG64(true, false); }
+                else { if (gh) WG64(false, true); else WG64(false, false); }
+    #undef WG64
+            } else if (!use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (w.cs > CO ? w.cs : CO) * 4.0 < 2.0e9 &&
+                       !getenv("DNNCA_WGRAD1")) {
+                const int mw = w.cs % 64 == 0 ? 4 : (w.cs % 32 == 0 ? 2 : 1);
+                const int tm = (4 / mw) < (4 / nn) ? (4 / mw) : (4 / nn);
+                const int nt2 = tiles_x * ((o.out.d.H + 8 * tm - 1) / (8 * tm)) * B;
+                const int combos2 = (w.cs / (16 * mw)) * (CO / (16 * nn));
+                int ps = (256 + combos2 - 1) / combos2;
+                if (ps > nt2) ps = nt2;
+                w.psplit = ps < 1 ? 1 : ps;
+                dim3 g2(w.psplit, w.cs / (16 * mw), CO / (16 * nn));
+                static const int wg2_narrow = getenv("DNNCA_WGRAD2_NARROW") != nullptr;        // tuning aid
+    #define WG2(MWv, NNv, NWv) LAUNCH(m, "ig_wgrad2", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad2<MWv, NNv, NWv>), g2, dim3(64 * NWv), 0, m->stream, w))
+    #define WG2N(MWv) do { if (nn == 4) WG2(MWv, 4, 4); \
+                           else if (nn == 2) { if (wg2_narrow) WG2(MWv, 2, 4); else WG2(MWv, 2, 8); } \
+                           else { if (wg2_narrow) WG2(MWv, 1, 4); else WG2(MWv, 1, 8); } } while (0)
+                if (mw == 4) WG2N(4); else if (mw == 2) WG2N(2); else WG2N(1);
+    #undef WG2N
+    #undef WG2
+            } else if (use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
+            else if (use_bf16(m, o) && nn == 2) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<2>), grid, dim3(256), 0, m->stream, w));
+            else if (nn == 4) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<4>), grid, dim3(256), 0, m->stream, w));
+            else if (nn == 2) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<2>), grid, dim3(256), 0, m->stream, w));
+            else LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<1>), grid, dim3(256), 0, m->stream, w));
+        }
+        if (bucketed)
+            LAUNCH(m, "wg_fold", 4.0 * WG_BUCKETS * (n_w + CO), 0,
+                   hipLaunchKernelGGL(ig::k_wg_fold, dim3((n_w + CO + 255) / 256), dim3(256), 0, m->stream, pl.wg_slabs, WG_BUCKETS,
+                                      WG_SLAB_FLOATS, n_w, m->g + o.w_off, m->g + o.b_off, CO));
+        if (side) m->wg_side_end(main_stream);
+    };
+    auto data_gradient = [&]() {
+        if (o.need_din) {
+            ig::ConvArgs a{};
+            a.src[0] = o.out.g.p; a.c_src0 = CO; a.c_src1 = 0;
+            a.src_half = o.out.g.h;
+            a.w = pl.flipped + o.w_off;
+            a.dst[0] = o.inA.g.p; a.dst[1] = o.inB.g.p;
+            a.n_dst0 = CA; a.n_dst1 = CB;
+            a.mask[0] = o.maskA ? o.inA.d.p : nullptr;
+            a.mask[1] = o.maskB ? o.inB.d.p : nullptr;
+            a.acc[0] = o.accA; a.acc[1] = o.accB;
+            a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
+            a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+            a.alpha = o.mask_alpha;
+            if (use_bf16(m, o))
+                launch_igb<1>(m, a, pl.wd + o.w_off, CA + CB, "igb_conv_dgrad", out_bytes + in_bytes, flops);
+            else
+                launch_ig<1>(m, a, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
+        }
+    };
+    // the fork sits in front of the data gradient (measured: forking behind it, so that the weight gradient meets only the next
+    // layer's HBM-bound BatchNorm passes, is 1.5 - 2.5 % slower on both dense configs; DNNCA_WG_LAST=1 selects that order)
+    static const bool wg_last = getenv("DNNCA_WG_LAST") != nullptr;
+    if (!wg_last) { weight_gradient(); data_gradient(); }
+    else { data_gradient(); weight_gradient(); }
     return true;
 }
 
