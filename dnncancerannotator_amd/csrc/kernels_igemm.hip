@@ -50,6 +50,8 @@ struct ConvArgs {
     // forward: batch statistics of the BatchNorm behind this conv ride in the epilogue of the persistent kernels:
     float* bn_part;          // [tile][2 * Cout] float partials (sum, sum of squares per channel); nullptr: none
     int src_half;            // the sources are stored as bf16 (View::h; k_igb_conv3 only)
+    int dst_half;            // forward, persistent kernels: dst[0] is stored as bf16 (the input of a BatchNorm, ig_plan_half)
+    int dsth[2];             // data gradient, persistent kernels: dst[k] is stored as bf16 (the gradient arriving at a BatchNorm)
 };
 
 // Epilogue of the persistent kernels (k_ig_conv3 / igb::k_igb_conv3), straight from the accumulator registers: lane (m16, q)
@@ -102,10 +104,31 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
                 for (int j = 0; j < NN; ++j) {
                     float t = v[i][j] + bias[j];
                     if (p.alpha >= 0.f) t = t > 0.f ? t : p.alpha * t;
+                    if (p.dst_half) t = (float)(hbf16)t;          // the batch statistics are those of the stored values
                     v[i][j] = t;
                     if (bn_on && ok[i]) { bs[j] += t; bq[j] = fmaf(t, t, bq[j]); }
                 }
         } else {
+            if (p.dsth[which]) {          // bf16 destination (never masked: the BatchNorm backward applies act')
+                hbf16* dh = reinterpret_cast<hbf16*>(dst);
+                if (p.acc[which]) {
+                    float t[4][NN];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NN; ++j) t[i][j] = ok[i] ? (float)dh[o[i] + 16 * j] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NN; ++j) v[i][j] += t[i][j];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NN; ++j)
+                        if (ok[i]) dh[o[i] + 16 * j] = (hbf16)v[i][j];
+                continue;
+            }
             if (p.acc[which]) {
                 float t[4][NN];
 #pragma unroll
@@ -128,6 +151,14 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
 #pragma unroll
                     for (int j = 0; j < NN; ++j) v[i][j] *= t[i][j] > 0.f ? 1.0f : p.alpha;
             }
+        }
+        if (MODE == 0 && p.dst_half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NN; ++j)
+                    if (ok[i]) reinterpret_cast<hbf16*>(dst)[o[i] + 16 * j] = (hbf16)v[i][j];
+            continue;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -735,6 +766,8 @@ struct TcArgs {
     int psplit;
     float alpha;
     float* bn_part;          // forward (bf16 kernel): [pixel block][2 * cout] partial batch statistics of the output for the BatchNorm behind it
+    int out_half;            // forward (bf16 kernel): out is stored as bf16 (the input of a BatchNorm, ig_plan_half)
+    int din_half;            // data gradient (bf16 kernel): din is stored as bf16 (the gradient arriving at a BatchNorm)
 };
 
 __device__ __forceinline__ size_t tc_outpix(int p, int a, int e, int H, int W) {
@@ -1910,8 +1943,14 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t
                 float* op = p.out + tc_outpix(px, ae >> 1, ae & 1, p.H, p.W) * p.cout + co0 + m16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float v = acc[ae][r][j][i] + bias[j];
-                    op[16 * j] = v;
+                    float v = acc[ae][r][j][i] + bias[j];
+                    if (p.out_half) {          // stored as bf16 (the input of a BatchNorm): the statistics are those of the stored values
+                        const hbf16 h = (hbf16)v;
+                        reinterpret_cast<hbf16*>(p.out)[(size_t)(op - p.out) + 16 * j] = h;
+                        v = (float)h;
+                    } else {
+                        op[16 * j] = v;
+                    }
                     bs[j] += v;
                     bq[j] = fmaf(v, v, bq[j]);
                 }
@@ -2002,6 +2041,12 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16
             for (int j = 0; j < 4; ++j) {
                 const size_t o = (size_t)px * p.cin + n0 + 16 * j + m16;
                 float v = acc[r][j][i];
+                if (p.din_half) {          // the gradient arriving at a BatchNorm, stored as bf16 (ig_plan_half; never masked)
+                    hbf16* dh = reinterpret_cast<hbf16*>(p.din);
+                    if (p.acc) v += (float)dh[o];
+                    dh[o] = (hbf16)v;
+                    continue;
+                }
                 if (p.acc) v += p.din[o];
                 if (p.mask) v *= p.mask[o] > 0.f ? 1.0f : p.alpha;
                 p.din[o] = v;
@@ -2191,6 +2236,34 @@ int ig_plan_half(Model* m) {
             else ok = false;
         }
         if (ok && users) hd[bn.out.d.p] = true;
+        // ... and so is the gradient that arrives at this BatchNorm: its writers are the backward passes of exactly those users
+        // (data-gradient epilogue of the persistent conv kernel, bf16 transposed-conv data gradient, pool backward by recorded
+        // positions; accumulation re-reads the bf16 value), its readers this BatchNorm's two backward passes.  DNNCA_NO_HALF_DY.
+        if (ok && users && dense(bn.out.g) && !getenv("DNNCA_NO_HALF_DY")) {
+            bool all_write = true;
+            for (const Op& c : m->ops) {
+                const bool a = c.inA.d.C && c.inA.d.p == bn.out.d.p, b = c.type == OP_CONV && c.inB.d.C && c.inB.d.p == bn.out.d.p;
+                if ((a || b) && c.type == OP_CONV && !c.need_din) all_write = false;
+                if ((a && c.maskA) || (b && c.maskB)) all_write = false;           // (BatchNorm nets never mask here)
+            }
+            if (all_write) hg[bn.out.g.p] = true;
+        }
+        // "bf16 activations" (BASELINE.md, configs[2]): the BatchNorm's input z -- written once by the conv / transposed conv in
+        // front of it (persistent bf16 kernels: rounded in the epilogue, batch statistics taken from the rounded values), read
+        // only by this BatchNorm's four passes -- is stored as bf16 as well.  Not a transparent change (z is rounded, 2^-9
+        // relative): DNNCA_NO_HALF_Z keeps it in f32.
+        if (!getenv("DNNCA_NO_HALF_Z") && dense(bn.inA.d)) {
+            int readers = 0;
+            const Op* prod = nullptr;
+            for (const Op& c : m->ops) {
+                if ((c.inA.d.C && c.inA.d.p == bn.inA.d.p) || (c.inB.d.C && c.inB.d.p == bn.inA.d.p)) ++readers;
+                if (c.out.d.C && c.out.d.p == bn.inA.d.p) prod = &c;
+            }
+            const bool pre = prod && (prod->type != OP_CONV || prod->alpha < 0.f || prod->premasked);     // no g_act_bwd pass reads z in f32
+            if (readers == 1 && pre &&
+                ((prod->type == OP_CONV && conv_ok(*prod)) || (prod->type == OP_TCONV && ig_tconv_supported(m, *prod) && use_bf16_tc(m, *prod))))
+                hd[bn.inA.d.p] = true;
+        }
         // the gradient this BN's backward writes: read only by the backward of the op that produced the BN's input
         if (bn.accA) continue;
         for (const Op& c : m->ops) {
@@ -2380,6 +2453,7 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
     a.tiles_y = (a.H + ig::TY - 1) / ig::TY;
     a.alpha = o.alpha;
     a.src_half = o.inA.d.h;          // ig_plan_half keeps both sources of a conv in the same format
+    a.dst_half = o.out.d.h;
     if (bn_next && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
         // the BatchNorm behind this conv takes its batch statistics from the conv's epilogue
         const int rows = conv3_rows(a, 4 * (use_bf16(m, o) ? igb_waves(a, o.out.d.C) : ig_waves(a, o.out.d.C)));     // one partial row per pixel tile
@@ -2509,6 +2583,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             a.mask[0] = o.maskA ? o.inA.d.p : nullptr;
             a.mask[1] = o.maskB ? o.inB.d.p : nullptr;
             a.acc[0] = o.accA; a.acc[1] = o.accB;
+            a.dsth[0] = o.inA.g.h; a.dsth[1] = o.inB.g.h;
             a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
             a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.alpha = o.mask_alpha;
@@ -2545,6 +2620,8 @@ static ig::TcArgs tc_args(Model* m, int B, Op& o) {
     a.dbias = m->g + o.b_off;
     a.acc = o.accA;
     a.cin = o.inA.d.C; a.cout = o.out.d.C;
+    a.out_half = o.out.d.h;
+    a.din_half = o.inA.g.h;
     a.H = o.inA.d.H; a.W = o.inA.d.W;
     a.npix = B * a.H * a.W;
     a.alpha = o.mask_alpha;

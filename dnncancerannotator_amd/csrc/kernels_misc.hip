@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void k_pool2_bwd(const float* __restrict__ in,
     }
 }
 
+template <bool DH>
 __global__ void k_pool2_bwd_idx(size_t nwin4, const float* __restrict__ dout, const unsigned* __restrict__ idx,
                                 float* __restrict__ din, int C, int H, int W, int acc);        // with the BN kernels below
 
@@ -133,9 +134,14 @@ bool fast_pool_bwd(Model* m, int B, Op& o, double bytes) {
         o.pool_idx_valid = false;
         const int C = o.out.d.C;
         const size_t nwin4 = (size_t)B * o.out.d.H * o.out.d.W * (C / 4);
-        LAUNCH(m, "pool2_bwd_idx", (double)nwin4 * (16 + 4 + (o.accA ? 128 : 64)), 0,
-               hipLaunchKernelGGL(k_pool2_bwd_idx, dim3((unsigned)((nwin4 + 255) / 256)), dim3(256), 0, m->stream, nwin4, o.out.g.p,
-                                  reinterpret_cast<const unsigned*>(o.pool_idx), o.inA.g.p, C, o.inA.d.H, o.inA.d.W, (int)o.accA));
+        if (o.inA.g.h)          // the gradient arriving at a BatchNorm, stored as bf16
+            LAUNCH(m, "pool2_bwd_idx", (double)nwin4 * (16 + 4 + (o.accA ? 64 : 32)), 0,
+                   hipLaunchKernelGGL(k_pool2_bwd_idx<true>, dim3((unsigned)((nwin4 + 255) / 256)), dim3(256), 0, m->stream, nwin4, o.out.g.p,
+                                      reinterpret_cast<const unsigned*>(o.pool_idx), o.inA.g.p, C, o.inA.d.H, o.inA.d.W, (int)o.accA));
+        else
+            LAUNCH(m, "pool2_bwd_idx", (double)nwin4 * (16 + 4 + (o.accA ? 128 : 64)), 0,
+                   hipLaunchKernelGGL(k_pool2_bwd_idx<false>, dim3((unsigned)((nwin4 + 255) / 256)), dim3(256), 0, m->stream, nwin4, o.out.g.p,
+                                      reinterpret_cast<const unsigned*>(o.pool_idx), o.inA.g.p, C, o.inA.d.H, o.inA.d.W, (int)o.accA));
         return true;
     }
     if (!fast_pool_supported(m, o)) return false;
@@ -604,8 +610,20 @@ bool fast_label_stats(Model* m, size_t n, const float* y) {
 // backward -> dgamma / dbeta.
 namespace dnnca {
 
+// four consecutive channels of a tensor stored as f32 or (View::h) as bf16; `elem` is the element offset
+template <bool H>
+__device__ __forceinline__ float4 ld4(const float* base, size_t elem) {
+    if constexpr (H) {
+        const hbf16x4 h = *reinterpret_cast<const hbf16x4*>(reinterpret_cast<const hbf16*>(base) + elem);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else {
+        return *reinterpret_cast<const float4*>(base + elem);
+    }
+}
+
 static inline bool bn_fast_ok(const View& x) { return x.ps == x.C && x.C % 4 == 0 && 256 % (x.C / 4) == 0 && x.C >= 16; }
 
+template <bool XH>      // XH: x is stored as bf16
 __global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float* __restrict__ x, int C, double* __restrict__ part) {
     __shared__ double red[256][8];
     const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
@@ -618,7 +636,7 @@ __global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float*
         const size_t p = k * chunk + pl;
         float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(x + (p + (size_t)u * PL) * C + 4 * cq);
+        for (int u = 0; u < U; ++u) v[u] = ld4<XH>(x, (p + (size_t)u * PL) * C + 4 * cq);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float*
     }
     if (blockIdx.x == gridDim.x - 1)
         for (size_t p = nfull * chunk + pl; p < npix; p += PL) {
-            const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * cq);
+            const float4 v = ld4<XH>(x, p * C + 4 * cq);
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             sq[0] = fmaf(v.x, v.x, sq[0]); sq[1] = fmaf(v.y, v.y, sq[1]); sq[2] = fmaf(v.z, v.z, sq[2]); sq[3] = fmaf(v.w, v.w, sq[3]);
         }
@@ -706,14 +724,14 @@ __global__ __launch_bounds__(1024) void k_bn_fold_bwd(int C, int nb, const float
     dbeta[c] += (float)b;
 }
 
-template <bool YH>      // YH: y is stored as bf16
+template <bool YH, bool XH>      // YH / XH: y / x is stored as bf16
 __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* __restrict__ x, float* __restrict__ y, int C,
                                                        int yps, const float* __restrict__ coef) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int G = C / 4, cq = (int)(i % G);
     const size_t p = i / G;
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 v = ld4<XH>(x, 4 * i);
     const float4 sc = *reinterpret_cast<const float4*>(coef + 4 * cq), sh = *reinterpret_cast<const float4*>(coef + C + 4 * cq);
     float4 o;
     o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
@@ -723,7 +741,7 @@ __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* _
 
 // BatchNorm apply + the MaxPool2D([2,2], 2) that follows it (components.py:54,59): one thread owns a 4-channel group of a 2 x 2
 // pixel window, writes the four normalised pixels and their maximum -- the pool pass never re-reads the normalised tensor.
-template <bool YH>
+template <bool YH, bool XH>
 __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const float* __restrict__ x, float* __restrict__ y,
                                                             float* __restrict__ pooled, unsigned* __restrict__ idx, int C, int H,
                                                             int W, const float* __restrict__ coef) {
@@ -742,7 +760,7 @@ __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const size_t o = p00 + ((size_t)(k >> 1) * W + (k & 1)) * C;
-        const float4 v = *reinterpret_cast<const float4*>(x + o);
+        const float4 v = ld4<XH>(x, o);
         float4 r;
         r.x = fmaf(v.x, sc.x, sh.x); r.y = fmaf(v.y, sc.y, sh.y); r.z = fmaf(v.z, sc.z, sh.z); r.w = fmaf(v.w, sc.w, sh.w);
         if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + o) = to_bf16x4(r);
@@ -760,6 +778,7 @@ __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const 
 }
 
 // MaxPool2D([2,2], 2) backward by the recorded positions: din = (acc ? din : 0) + route(dout); one thread = a 4-channel group of a window
+template <bool DH>      // DH: din is stored as bf16
 __global__ __launch_bounds__(256) void k_pool2_bwd_idx(size_t nwin4, const float* __restrict__ dout, const unsigned* __restrict__ idx,
                                                        float* __restrict__ din, int C, int H, int W, int acc) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -774,16 +793,18 @@ __global__ __launch_bounds__(256) void k_pool2_bwd_idx(size_t nwin4, const float
     const size_t p00 = ((b * H + 2 * yp) * W + 2 * xp) * C + 4 * cq;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float4* o = reinterpret_cast<float4*>(din + p00 + ((size_t)(k >> 1) * W + (k & 1)) * C);
-        float4 r = acc ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t e = p00 + ((size_t)(k >> 1) * W + (k & 1)) * C;
+        float4 r = acc ? ld4<DH>(din, e) : make_float4(0.f, 0.f, 0.f, 0.f);
         if ((where & 0xffu) == (unsigned)k) r.x += g.x;
         if (((where >> 8) & 0xffu) == (unsigned)k) r.y += g.y;
         if (((where >> 16) & 0xffu) == (unsigned)k) r.z += g.z;
         if ((where >> 24) == (unsigned)k) r.w += g.w;
-        *o = r;
+        if (DH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(din) + e) = to_bf16x4(r);
+        else *reinterpret_cast<float4*>(din + e) = r;
     }
 }
 
+template <bool XH, bool GH>      // XH / GH: x / dy is stored as bf16
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const float* __restrict__ x, const float* __restrict__ dy,
                                                             int C, int dps, const float* __restrict__ coef,
                                                             float* __restrict__ part) {
@@ -801,8 +822,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
         float4 v[U], d[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            v[u] = *reinterpret_cast<const float4*>(x + (p + (size_t)u * PL) * C + 4 * cq);
-            d[u] = *reinterpret_cast<const float4*>(dy + (p + (size_t)u * PL) * dps + 4 * cq);
+            v[u] = ld4<XH>(x, (p + (size_t)u * PL) * C + 4 * cq);
+            d[u] = ld4<GH>(dy, (p + (size_t)u * PL) * dps + 4 * cq);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -813,8 +834,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
     }
     if (blockIdx.x == gridDim.x - 1)
         for (size_t p = nfull * chunk + pl; p < npix; p += PL) {
-            const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * cq);
-            const float4 d = *reinterpret_cast<const float4*>(dy + p * dps + 4 * cq);
+            const float4 v = ld4<XH>(x, p * C + 4 * cq);
+            const float4 d = ld4<GH>(dy, p * dps + 4 * cq);
             sg[0] = fmaf(d.x, (v.x - mean.x) * inv.x, sg[0]); sg[1] = fmaf(d.y, (v.y - mean.y) * inv.y, sg[1]);
             sg[2] = fmaf(d.z, (v.z - mean.z) * inv.z, sg[2]); sg[3] = fmaf(d.w, (v.w - mean.w) * inv.w, sg[3]);
             sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
@@ -829,7 +850,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
     }
 }
 
-template <bool DH>      // DH: dx is stored as bf16 (never accumulated into)
+template <bool DH, bool XH, bool GH>      // DH: dx is stored as bf16 (never accumulated into); XH / GH: x / dy are
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dx, int C, int dps, int acc,
                                                            const float* __restrict__ coef, const float* __restrict__ gamma,
@@ -839,8 +860,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
     if (i >= n4) return;
     const int G = C / 4, cq = (int)(i % G);
     const size_t p = i / G;
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 d = *reinterpret_cast<const float4*>(dy + p * dps + 4 * cq);
+    const float4 v = ld4<XH>(x, 4 * i);
+    const float4 d = ld4<GH>(dy, p * dps + 4 * cq);
     const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
     const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * cq);
     const float4 dg = *reinterpret_cast<const float4*>(dgamma + 4 * cq), db = *reinterpret_cast<const float4*>(dbeta + 4 * cq);
@@ -913,8 +934,12 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
             const unsigned nb = bn_blocks(npix, C);
             double* part = nullptr;
             DN_TRYB(bn_scratch(m, (size_t)nb * 2 * C * 8, (void**)&part));
-            LAUNCH(m, "bn_stats", tb, 3 * tb / 4,
-                   hipLaunchKernelGGL(k_bn_stats_fast, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, part));
+            if (o.inA.d.h)
+                LAUNCH(m, "bn_stats", tb / 2, 3 * tb / 4,
+                       hipLaunchKernelGGL(k_bn_stats_fast<true>, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, part));
+            else
+                LAUNCH(m, "bn_stats", tb, 3 * tb / 4,
+                       hipLaunchKernelGGL(k_bn_stats_fast<false>, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, part));
             LAUNCH(m, "bn_fold_stats", 16.0 * nb * C, 0,
                    hipLaunchKernelGGL((k_bn_fold_stats<32, double>), dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, (double)npix,
                                       (const double*)part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off, m->state + o.mv_off,
@@ -934,23 +959,23 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
         pool->pool_idx_valid = m->dry || pool->pool_idx != nullptr;     // the dry run lists the launches of the real one
         const dim3 grid((unsigned)((n4 / 4 + 255) / 256));
         unsigned* ix = reinterpret_cast<unsigned*>(pool->pool_idx);
-        if (o.out.d.h)
-            LAUNCH(m, "bn_apply_pool", 1.75 * tb, tb / 2,
-                   hipLaunchKernelGGL(k_bn_apply_pool_fast<true>, grid, dim3(256), 0, m->stream, n4 / 4, o.inA.d.p, o.out.d.p,
-                                      pool->out.d.p, ix, C, o.inA.d.H, o.inA.d.W, o.coef));
-        else
-            LAUNCH(m, "bn_apply_pool", 2.25 * tb, tb / 2,
-                   hipLaunchKernelGGL(k_bn_apply_pool_fast<false>, grid, dim3(256), 0, m->stream, n4 / 4, o.inA.d.p, o.out.d.p,
-                                      pool->out.d.p, ix, C, o.inA.d.H, o.inA.d.W, o.coef));
+        // bytes: x in (f32 or bf16), y out (f32 or bf16), pooled out (a quarter, f32)
+        const double pb = tb * ((o.inA.d.h ? 0.5 : 1.0) + (o.out.d.h ? 0.5 : 1.0) + 0.25);
+#define BNPOOL(YHv, XHv) LAUNCH(m, "bn_apply_pool", pb, tb / 2,                                                              \
+        hipLaunchKernelGGL((k_bn_apply_pool_fast<YHv, XHv>), grid, dim3(256), 0, m->stream, n4 / 4, o.inA.d.p, o.out.d.p,    \
+                           pool->out.d.p, ix, C, o.inA.d.H, o.inA.d.W, o.coef))
+        if (o.out.d.h) { if (o.inA.d.h) BNPOOL(true, true); else BNPOOL(true, false); }
+        else { if (o.inA.d.h) BNPOOL(false, true); else BNPOOL(false, false); }
+#undef BNPOOL
         return true;
     }
     const dim3 grid((unsigned)((n4 + 255) / 256));
-    if (o.out.d.h)
-        LAUNCH(m, "bn_apply", 1.5 * tb, tb / 2,
-               hipLaunchKernelGGL(k_bn_apply_fast<true>, grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.d.p, C, o.out.d.ps, o.coef));
-    else
-        LAUNCH(m, "bn_apply", 2 * tb, tb / 2,
-               hipLaunchKernelGGL(k_bn_apply_fast<false>, grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.d.p, C, o.out.d.ps, o.coef));
+    const double ab = tb * ((o.inA.d.h ? 0.5 : 1.0) + (o.out.d.h ? 0.5 : 1.0));
+#define BNAPPLY(YHv, XHv) LAUNCH(m, "bn_apply", ab, tb / 2,                                                                  \
+        hipLaunchKernelGGL((k_bn_apply_fast<YHv, XHv>), grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.d.p, C, o.out.d.ps, o.coef))
+    if (o.out.d.h) { if (o.inA.d.h) BNAPPLY(true, true); else BNAPPLY(true, false); }
+    else { if (o.inA.d.h) BNAPPLY(false, true); else BNAPPLY(false, false); }
+#undef BNAPPLY
     return true;
 }
 
@@ -966,24 +991,28 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
     const unsigned nb = bn_blocks(npix, C);
     float* part = nullptr;
     DN_TRYB(bn_scratch(m, (size_t)nb * 2 * C * 8, (void**)&part));
-    LAUNCH(m, "bn_bwd_reduce", 2 * tb, tb,
-           hipLaunchKernelGGL(k_bn_bwd_reduce_fast, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C,
-                              o.out.g.ps, o.coef, part));
+    const bool xh = o.inA.d.h != 0, gh = o.out.g.h != 0, dh = o.inA.g.h != 0;
+    const double rb = tb * ((xh ? 0.5 : 1.0) + (gh ? 0.5 : 1.0));
+#define BNRED(XHv, GHv) LAUNCH(m, "bn_bwd_reduce", rb, tb,                                                                   \
+        hipLaunchKernelGGL((k_bn_bwd_reduce_fast<XHv, GHv>), dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C, \
+                           o.out.g.ps, o.coef, part))
+    if (xh) { if (gh) BNRED(true, true); else BNRED(true, false); }
+    else { if (gh) BNRED(false, true); else BNRED(false, false); }
+#undef BNRED
     LAUNCH(m, "bn_fold_bwd", 8.0 * nb * C, 0,
            hipLaunchKernelGGL(k_bn_fold_bwd, dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, part, m->g + o.w_off,
                               m->g + o.b_off));
     const size_t n4 = npix * (C / 4);
     const dim3 grid((unsigned)((n4 + 255) / 256));
-    if (o.inA.g.h)
-        LAUNCH(m, "bn_bwd_apply", 2.5 * tb, 2 * tb,
-               hipLaunchKernelGGL(k_bn_bwd_apply_fast<true>, grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.g.p, o.inA.g.p, C,
-                                  o.out.g.ps, 0, o.coef, m->p + o.w_off, m->g + o.w_off, m->g + o.b_off,
-                                  (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha));
-    else
-        LAUNCH(m, "bn_bwd_apply", 3 * tb, 2 * tb,
-               hipLaunchKernelGGL(k_bn_bwd_apply_fast<false>, grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.g.p, o.inA.g.p, C,
-                                  o.out.g.ps, (int)o.accA, o.coef, m->p + o.w_off, m->g + o.w_off, m->g + o.b_off,
-                                  (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha));
+#define BNBWD(DHv, XHv, GHv) LAUNCH(m, "bn_bwd_apply", rb + tb * (DHv ? 0.5 : 1.0), 2 * tb,                                  \
+        hipLaunchKernelGGL((k_bn_bwd_apply_fast<DHv, XHv, GHv>), grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.g.p,     \
+                           o.inA.g.p, C, o.out.g.ps, DHv ? 0 : (int)o.accA, o.coef, m->p + o.w_off, m->g + o.w_off,          \
+                           m->g + o.b_off, (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha))
+#define BNBWD2(DHv, XHv) do { if (gh) BNBWD(DHv, XHv, true); else BNBWD(DHv, XHv, false); } while (0)
+    if (dh) { if (xh) BNBWD2(true, true); else BNBWD2(true, false); }
+    else { if (xh) BNBWD2(false, true); else BNBWD2(false, false); }
+#undef BNBWD2
+#undef BNBWD
     return true;
 }
 

@@ -33,7 +33,11 @@ enum { DNNCA_ARCH_UNET = 0, DNNCA_ARCH_MULMO = 1 };     /* models/tf_models/unet
 enum { DNNCA_PAD_VALID = 0, DNNCA_PAD_SAME = 1 };       /* model_options.padding (configs/unet.yaml:9) */
 /* arithmetic type of the conv contractions.  DNNCA_BF16: the operands of the 3x3 convolutions with >= 32 channels and of the
    transposed convolutions with channel counts that are multiples of 64 are rounded to bfloat16 (round to nearest even) on
-   their way into the matrix cores; weights, activations, gradients and every accumulation stay float32 */
+   their way into the matrix cores; weights, optimizer state, BatchNorm statistics and every accumulation stay float32.
+   Activations ("bf16 acts", BASELINE.md configs[2]): tensors whose every reader rounds them anyway are kept as bfloat16 in
+   HBM (bit-identical results), and so are -- this does round -- the input of a BatchNorm written by a 64-channel-multiple
+   conv / transposed conv (batch statistics are those of the stored values) and the gradient arriving at a BatchNorm whose
+   users are all such layers or a 2x2 max-pool.  DNNCA_NO_HALF_Z / DNNCA_NO_HALF_DY in the environment keep those in float32 */
 enum { DNNCA_F32 = 0, DNNCA_BF16 = 1 };
 enum { DNNCA_UNIQUE_ID_BYTES = 128 };
 

@@ -4,7 +4,11 @@ runs; the library reads the variable once per process).  Prints one JSON line.
 
 dtype bf16: the implicit-GEMM kernels round their operands (activations, gradients, weights) to bf16 while staging and
 accumulate in fp32.  The oracle is made to do exactly that (operands of every 3x3 conv and every 64-multiple transposed conv
-rounded to bf16, float64 accumulation), so the comparison isolates the kernels' indexing from bf16 noise."""
+rounded to bf16, float64 accumulation), so the comparison isolates the kernels' indexing from bf16 noise.
+With BatchNorm ("bf16 activations", BASELINE.md configs[2]) the outputs of the 64-channel-multiple convs / transposed convs
+that feed a BatchNorm are stored as bf16 as well (ig_plan_half): the oracle rounds those outputs too (round_z).
+With BatchNorm the gradients that arrive at a BatchNorm from the 64-channel kernels are stored as bf16 (round_dy).
+"""
 
 import json
 import os
@@ -29,15 +33,41 @@ def to_bf16(a):
 class bf16_oracle:
     """context manager: every 3x3 conv / 64-multiple transposed conv of the oracle contracts bf16-rounded operands"""
 
+    def __init__(self, round_z=False):
+        self.round_z = round_z
+
     def __enter__(self):
+        round_z = self.round_z
         self.saved = (O.conv2d_fwd, O.conv2d_bwd, O.tconv_fwd, O.tconv_bwd)
+        self.saved_bn = O.bn_bwd
         fwd0, bwd0, tfwd0, tbwd0 = self.saved
+        bn_bwd0 = O.bn_bwd
+        calls = [0]
+
+        def bn_bwd(cache, dy):
+            # the gradient arriving at a BatchNorm whose users are all 64-channel bf16 kernels is stored as bf16: in these
+            # networks every BatchNorm but the last one (the first whose backward runs: it feeds the head)
+            calls[0] += 1
+            if round_z and calls[0] > 1 and dy.shape[-1] % 64 == 0:
+                dy = to_bf16(dy)
+            return bn_bwd0(cache, dy)
+
+        O.bn_bwd = bn_bwd
 
         def tc_bf16(w):
             return w.shape[2] % 64 == 0 and w.shape[3] % 64 == 0
 
         def tfwd(x, w, b):
-            return tfwd0(to_bf16(x), to_bf16(w), b) if tc_bf16(w) else tfwd0(x, w, b)
+            if not tc_bf16(w):
+                return tfwd0(x, w, b)
+            out = tfwd0(to_bf16(x), to_bf16(w), b)
+            if round_z:                      # (y, cache): the BatchNorm behind it reads the stored (rounded) values
+                out = (to_bf16(out[0]),) + tuple(out[1:])
+            return out
+
+        def z_half(w):         # conv_ok() of ig_plan_half: every source and the output a multiple of 64 channels
+            cin, cout = w.shape[2], w.shape[3]
+            return cout % 64 == 0 and (cin == 2 * cout or cin % 64 == 0)      # cin == 2 cout: the decoder's two-source conv
 
         def tbwd(cache, dy):
             return tbwd0(cache, to_bf16(dy)) if tc_bf16(cache[1]) else tbwd0(cache, dy)
@@ -48,7 +78,12 @@ class bf16_oracle:
         def fwd(x, w, b, padding, alpha=None):
             if not dense(w):
                 return fwd0(x, w, b, padding, alpha)
-            return fwd0(to_bf16(x), to_bf16(w), b, padding, alpha)
+            if not (round_z and z_half(w)):
+                return fwd0(to_bf16(x), to_bf16(w), b, padding, alpha)
+            y, cache = fwd0(to_bf16(x), to_bf16(w), b, padding, alpha)
+            y = to_bf16(y)
+            xp, wc, yv, al, pad, xshape = cache
+            return y, (xp, wc, y, al, pad, xshape)       # act' in the backward pass sees the stored values
 
         def bwd(cache, dy):
             xp, w, yv, alpha, padding, xshape = cache
@@ -62,6 +97,7 @@ class bf16_oracle:
 
     def __exit__(self, *exc):
         O.conv2d_fwd, O.conv2d_bwd, O.tconv_fwd, O.tconv_bwd = self.saved
+        O.bn_bwd = self.saved_bn
 
 
 def run(device, f0, S, B=2, bn=False, cin=32, n_down=2):
@@ -74,7 +110,7 @@ def run(device, f0, S, B=2, bn=False, cin=32, n_down=2):
     x = rng.random((B, S, S, cin)).astype(np.float32)
     _, y = O.synthetic_batch(B, S, S, 1)
     cfg = dict(weight_mul=3.0)
-    with bf16_oracle():
+    with bf16_oracle(round_z=bn):
         loss, grads, logits, _ = O.loss_and_grads(spec, params, x.astype(np.float64), y, cfg, training=True)
     m = device.DeviceModel('unet', cin, S, S, B, dtype='bf16', **opts)
     m.set_params(O.flatten(spec, params))
