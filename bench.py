@@ -100,8 +100,9 @@ def main():
     C, BATCH_PER_GPU = wl['C'], wl['batch']
     model = dev.DeviceModel(wl['arch'], C, H, W, BATCH_PER_GPU, force_generic=args.generic, dtype=wl['dtype'], **wl['opts'])
     model.init_glorot(seed=2)          # same weights on every rank (random-init weights of the named architecture)
-    uid = distributed.exchange_unique_id(ctx, dev.DeviceModel)     # 128-byte RCCL id through a file keyed by the launcher's pid
-    model.comm_init(rank, world, uid)
+    if world > 1:                      # (one GPU: no communicator -- the single-replica step keeps its fused fold + Adam launch)
+        uid = distributed.exchange_unique_id(ctx, dev.DeviceModel)     # 128-byte RCCL id through a file keyed by the launcher's pid
+        model.comm_init(rank, world, uid)
 
     # rank-local shard of the global batch, resident in HBM before the timed region
     x, y = synthetic_batch(BATCH_PER_GPU, H, W, C, seed_x=100 + rank, seed_y=200 + rank)

@@ -121,11 +121,11 @@ struct Model {
     // elementwise, so the result is bit-identical to the single call.
     hipStream_t comm_stream = nullptr;
     // Weight gradients of the dense (igemm) convs are leaves of the backward pass: nothing reads them before the optimizer step.
-    // Single-replica train steps launch them on a second, low-priority stream (fork: an event behind the kernel that produced
+    // Train steps launch them on a second, low-priority stream (fork: an event behind the kernel that produced
     // the conv's output gradient; join: one event at the end of the backward pass), where they run beside the HBM-bound
     // BatchNorm passes and data-gradient convs of the main chain instead of in front of them.
     hipStream_t wg_stream = nullptr;
-    hipEvent_t wg_fork = nullptr, wg_join = nullptr;
+    hipEvent_t wg_fork = nullptr, wg_join = nullptr, wg_bucket = nullptr;
     bool wg_pending = false;             // the side stream holds work of this backward pass
     bool wg_side_begin();                // fork: later launches on `stream` go to the side stream; false: not in this mode
     void wg_side_end(hipStream_t main);  // back to the main stream

@@ -46,15 +46,16 @@ Model::~Model() {
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     if (wg_fork) (void)hipEventDestroy(wg_fork);
     if (wg_join) (void)hipEventDestroy(wg_join);
+    if (wg_bucket) (void)hipEventDestroy(wg_bucket);
     if (wg_stream) (void)hipStreamDestroy(wg_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
 bool Model::wg_side_begin() {
     static const bool off = getenv("DNNCA_NO_WG_STREAM") != nullptr;
-    // profiles time one launch after the other; the dry run launches nothing; with a communicator the gradient buckets follow the
-    // main stream's order
-    if (off || dry || prof_mode || comm || !merged_launches()) return false;
+    // full profiles (modes 1, 3) time one launch after the other (the sampled bracket of mode 2 goes where its kernel goes); the
+    // dry run launches nothing.  (With a communicator a gradient bucket also waits for the side stream: send_bucket.)
+    if (off || dry || prof_mode == 1 || prof_mode == 3) return false;
     if (!wg_stream) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo: the numerically largest = least urgent
@@ -62,10 +63,11 @@ bool Model::wg_side_begin() {
         const int prio = !pe || atoi(pe) == 1 ? lo : (atoi(pe) == 2 ? hi : 0);
         if (hipStreamCreateWithPriority(&wg_stream, hipStreamNonBlocking, prio) != hipSuccess) { wg_stream = nullptr; return false; }
         if (hipEventCreateWithFlags(&wg_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&wg_join, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&wg_join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&wg_bucket, hipEventDisableTiming) != hipSuccess)
             return false;
     }
-    if (!wg_fork || !wg_join) return false;
+    if (!wg_fork || !wg_join || !wg_bucket) return false;
     if (hipEventRecord(wg_fork, stream) != hipSuccess || hipStreamWaitEvent(wg_stream, wg_fork, 0) != hipSuccess) return false;
     wg_pending = true;
     stream = wg_stream;
@@ -756,6 +758,10 @@ int Model::send_bucket(int64_t lo, int64_t hi) {
     }
     HIP_TRY(hipEventRecord(ev_bucket, stream));
     HIP_TRY(hipStreamWaitEvent(comm_stream, ev_bucket, 0));
+    if (wg_pending) {          // weight gradients of the bucket's layers may still be running on the side stream (FIFO: one event covers them)
+        HIP_TRY(hipEventRecord(wg_bucket, wg_stream));
+        HIP_TRY(hipStreamWaitEvent(comm_stream, wg_bucket, 0));
+    }
     ncclResult_t r = ncclAllReduce(g + lo, g + lo, (size_t)(hi - lo), ncclFloat, ncclSum, comm, comm_stream);
     if (r != ncclSuccess) { set_error("ncclAllReduce(bucket): %s", ncclGetErrorString(r)); return DNNCA_ECOMM; }
     ++collectives_last_step;

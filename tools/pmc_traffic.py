@@ -19,8 +19,8 @@ def short_name(k):
     k = re.sub(r'^void ', '', k)
     m = re.match(r'dnnca::k_pgbwd<(\d+), (\d+), (\d+), (true|false)((?:, \w+)*)>', k)
     if m:
-        rest = [t.strip() for t in m.group(5).split(',') if t.strip()]      # NT, DB, VW, PF, TCF
-        kind = 'tc_' if len(rest) >= 5 and rest[4] == 'true' else ('pool_' if len(rest) >= 4 and rest[3] == 'true' else '')
+        rest = [t.strip() for t in m.group(5).split(',') if t.strip()]      # NT, DB, VW, PF, TCF, TCM
+        kind = 'tc_' if 'true' in rest[4:6] else ('pool_' if len(rest) >= 4 and rest[3] == 'true' else '')
         return 'pgbwd_%s%s%sx%s_%s' % ('' if m.group(4) == 'true' else 'w_', kind, m.group(1), m.group(2), m.group(3))
     m = re.match(r'dnnca::k_pgfwd<(\d+), (\d+), (\d+), \d+, (?:true|false)(, true)?>', k)
     if m:
@@ -31,13 +31,15 @@ def short_name(k):
     m = re.match(r'dnnca::k_(tconv2_fwd|tconv_bwd)<(\d+), (\d+)', k)
     if m:
         return '%s_%s_%s' % m.groups()
-    m = re.match(r'dnnca::fz::k_fz_(down|up)<(\d+), (\d+)', k)
+    m = re.match(r'dnnca::fz::k_fz_(down|up)<(\d+), (\d+)((?:, \d+)*)>', k)
     if m:
-        return 'fz_%s_%s_%s' % m.groups()
+        extra = [t.strip() for t in m.group(4).split(',') if t.strip()]     # TW, TH, NT, MINW[, NF]
+        ride = 'tc_' if m.group(1) == 'up' and len(extra) >= 5 and extra[4] != '0' else ''
+        return 'fz_%s_%s%s_%s' % (m.group(1), ride, m.group(2), m.group(3))
     m = re.match(r'dnnca::k_bwd3v<(true|false)', k)
     if m:
         return 'bwd3v_pool_3x1_3' if m.group(1) == 'true' else 'bwd3v_3x1_3'
-    for kern, name in (('k_tail3<', 'tail3_3x1_3'), ('k_first3_fwd<', 'first3_fwd'), ('k_first3<', 'first3_bwd')):
+    for kern, name in (('k_tail3<', 'tail3_3x1_3'), ('k_first3_fwd<', 'first3_fwd'), ('k_first3<', 'first3_bwd'), ('k_up3_fwd<', 'up3_fwd')):
         if k.startswith('dnnca::' + kern):
             return name
     m = re.match(r'dnnca::(?:ig::|igb::|first::)?k_(\w+)', k)
