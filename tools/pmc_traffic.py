@@ -22,9 +22,9 @@ def short_name(k):
         rest = [t.strip() for t in m.group(5).split(',') if t.strip()]      # NT, DB, VW, PF, TCF, TCM
         kind = 'tc_' if 'true' in rest[4:6] else ('pool_' if len(rest) >= 4 and rest[3] == 'true' else '')
         return 'pgbwd_%s%s%sx%s_%s' % ('' if m.group(4) == 'true' else 'w_', kind, m.group(1), m.group(2), m.group(3))
-    m = re.match(r'dnnca::k_pgfwd<(\d+), (\d+), (\d+), \d+, (?:true|false)(, true)?>', k)
+    m = re.match(r'dnnca::k_pgfwd<(\d+), (\d+), (\d+), \d+, (?:true|false)(, true|, false)?>', k)
     if m:
-        return 'pgfwd_%s%sx%s_%s' % ('head_' if m.group(4) else '', m.group(1), m.group(2), m.group(3))
+        return 'pgfwd_%s%sx%s_%s' % ('head_' if m.group(4) == ', true' else '', m.group(1), m.group(2), m.group(3))
     m = re.match(r'dnnca::k_(pool2_bwd|pool2_fwd|head_train|head_reduce)<(\d+)', k)
     if m:
         return '%s_%s' % m.groups()
