@@ -52,7 +52,7 @@ Model::~Model() {
 }
 
 bool Model::wg_side_begin() {
-    static const bool off = getenv("DNNCA_NO_WG_STREAM") != nullptr;
+    const bool off = getenv("DNNCA_NO_WG_STREAM") != nullptr;          // read per call: the tests flip it
     // full profiles (modes 1, 3) time one launch after the other (the sampled bracket of mode 2 goes where its kernel goes); the
     // dry run launches nothing.  (With a communicator a gradient bucket also waits for the side stream: send_bucket.)
     if (off || dry || prof_mode == 1 || prof_mode == 3) return false;

@@ -359,6 +359,32 @@ def test_bf16_storage_of_rounded_tensors_is_transparent(gpu, monkeypatch, arch, 
     assert np.abs(gh - gf).max() <= 1e-5 * np.abs(gf).max()
 
 
+@pytest.mark.parametrize('arch, C, dtype, opts, size', [('unet', 1, 'bf16', dict(n_filters_first=64, n_downsample=2), 64),
+                                                       ('mulmo', 3, 'f32', dict(n_filters_first=16, n_downsample=2), 64)])
+def test_weight_gradients_on_the_side_stream_change_nothing(gpu, monkeypatch, arch, C, dtype, opts, size):
+    """The dense convs' weight gradients run on a second stream beside the main chain (Model::wg_side_begin): same kernels, same
+    operands, so loss, BatchNorm state and every gradient tensor equal the single-stream run up to the summation order of the
+    float atomics.  Three steps on three different batches at learning rate 0 (the weights stay put, so the steps do not amplify
+    that noise): a missing fork / join dependency -- a weight gradient still running when the next step zeroes the gradient
+    vector or rewrites the activations -- would show in the third step's gradient."""
+    opts = dict(rate=2, kernel_size=3, conv_stride=1, padding='same', bn=True, **opts)
+    spec = O.ModelSpec(arch, C, **opts)
+    batches = [O.synthetic_batch(2, size, size, C, seed_x=10 + k, seed_y=20 + k) for k in range(3)]
+    res = []
+    for single in (False, True):
+        if single:
+            monkeypatch.setenv('DNNCA_NO_WG_STREAM', '1')
+        m = gpu.DeviceModel(arch, C, size, size, 2, dtype=dtype, **opts)
+        m.init_glorot(seed=4)
+        losses = [m.train_step(x, y, 0.0, m.loss_cfg(weight_mul=3.0)).loss for x, y in batches]
+        res.append((losses, m.get_grads().astype(np.float64), m.get_state().copy()))
+        m.close()
+    (l1, g1, s1), (l0, g0, s0) = res
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    Hp.assert_grads_per_tensor_nofixture(spec, g1, g0, 2e-5, what='side stream vs one stream (third step)')
+    assert np.abs(s1 - s0).max() <= 1e-6 * max(1.0, np.abs(s0).max())
+
+
 def test_cli_train_then_evaluate_on_tfrecords(gpu, tmp_path):
     """`python3 -m annotator train|evaluate` with the reference's YAML surface and .tfrecords exam files, in a child
     process (the documented drop-in invocation)."""
