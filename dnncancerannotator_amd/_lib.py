@@ -91,6 +91,12 @@ SIGNATURES = {
     'dnnca_forward_dev': (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     'dnnca_last_step_out': (C.c_int, [_VP, C.POINTER(StepOut)]),
     'dnnca_sync': (C.c_int, [_VP]),
+    'dnnca_stage_init': (C.c_int, [_VP, C.c_int, C.c_size_t]),
+    'dnnca_stage_upload': (C.c_int, [_VP, C.c_int, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(_VP), C.POINTER(_VP)]),
+    'dnnca_stage_uploaded': (C.c_int, [_VP, C.c_int]),
+    'dnnca_stage_wait': (C.c_int, [_VP, C.c_int]),
+    'dnnca_train_step_staged': (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int, C.c_float, C.POINTER(LossCfg)]),
+    'dnnca_staged_out': (C.c_int, [_VP, C.c_int, C.POINTER(StepOut)]),
     'dnnca_pixel_confusion': (C.c_int, [_VP, _FP, C.c_int, _FP, C.c_int, C.POINTER(Confusion)]),
     'dnnca_pixel_confusion_of': (C.c_int, [_VP, _FP, _FP, C.c_int64, _FP, C.c_int, C.POINTER(Confusion)]),
     'dnnca_comm_unique_id': (C.c_int, [_VP]),

@@ -557,9 +557,17 @@ __global__ __launch_bounds__(256) void k_wg_fold(float* __restrict__ slabs, int 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_w + n_b) return;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) {
-        s += slabs[(size_t)b * stride + i];
-        slabs[(size_t)b * stride + i] = 0.f;
+    constexpr int U = 8;                 // eight copies in flight per thread (the loop used to wait for every single load)
+    for (int b0 = 0; b0 < nb; b0 += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = slabs[(size_t)min(b0 + u, nb - 1) * stride + i];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (b0 + u < nb) {
+                s += v[u];
+                slabs[(size_t)(b0 + u) * stride + i] = 0.f;
+            }
     }
     if (i < n_w) dw[i] += s;
     else dbias[i - n_w] += s;

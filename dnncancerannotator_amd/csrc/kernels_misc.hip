@@ -674,17 +674,44 @@ __device__ __forceinline__ void bn_fold(const TP* __restrict__ part, int nb, int
     constexpr int RL = 1024 / CPB;
     const int cl = threadIdx.x % CPB, r = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
     double s0 = 0.0, s1 = 0.0;
-    if (c < C)
-        for (int b = r; b < nb; b += RL) {
-            s0 += (double)part[(size_t)b * 2 * C + c];
-            s1 += (double)part[(size_t)b * 2 * C + C + c];
+    if (c < C) {
+        // eight rows (sixteen loads) in flight per thread: the fold is a chain of memory round trips, not bandwidth
+        constexpr int U = 8;
+        for (int b = r; b < nb; b += U * RL) {
+            TP v0[U], v1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {       // rows past the end: the last row again, not added
+                const int bb = min(b + u * RL, nb - 1);
+                v0[u] = part[(size_t)bb * 2 * C + c];
+                v1[u] = part[(size_t)bb * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (b + u * RL < nb) { s0 += (double)v0[u]; s1 += (double)v1[u]; }
         }
+    }
     red[(r * CPB + cl) * 2] = s0;
     red[(r * CPB + cl) * 2 + 1] = s1;
     __syncthreads();
     a0 = 0.0; a1 = 0.0;
-    if (r == 0)
-        for (int l = 0; l < RL; ++l) { a0 += red[(l * CPB + cl) * 2]; a1 += red[(l * CPB + cl) * 2 + 1]; }
+    if constexpr (RL > 32) {          // two levels: row lanes 0..7 fold RL/8 lanes each, lane 0 folds those eight
+        constexpr int SUB = RL / 8;
+        double t0 = 0.0, t1 = 0.0;
+        if (r < 8) {
+#pragma unroll 8
+            for (int l = r * SUB; l < (r + 1) * SUB; ++l) { t0 += red[(l * CPB + cl) * 2]; t1 += red[(l * CPB + cl) * 2 + 1]; }
+        }
+        __syncthreads();
+        if (r < 8) { red[(r * CPB + cl) * 2] = t0; red[(r * CPB + cl) * 2 + 1] = t1; }
+        __syncthreads();
+        if (r == 0)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) { a0 += red[(l * CPB + cl) * 2]; a1 += red[(l * CPB + cl) * 2 + 1]; }
+    } else {
+        if (r == 0)
+#pragma unroll 8
+            for (int l = 0; l < RL; ++l) { a0 += red[(l * CPB + cl) * 2]; a1 += red[(l * CPB + cl) * 2 + 1]; }
+    }
 }
 
 // raw moments -> coefficients (and the moving statistics in training): same contract as g_bn_finalize
@@ -717,9 +744,9 @@ __global__ __launch_bounds__(1024) void k_bn_fold_bwd(int C, int nb, const float
                                                       float* __restrict__ dbeta) {
     __shared__ double red[2048];
     double g, b;
-    bn_fold<32>(part, nb, C, g, b, red);
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    bn_fold<8>(part, nb, C, g, b, red);          // 8 channels x 128 row lanes per block: at most four rows per thread for 512 rows
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    if ((threadIdx.x >> 3) != 0 || c >= C) return;
     dgamma[c] += (float)g;
     dbeta[c] += (float)b;
 }
@@ -1000,7 +1027,7 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
     else { if (gh) BNRED(false, true); else BNRED(false, false); }
 #undef BNRED
     LAUNCH(m, "bn_fold_bwd", 8.0 * nb * C, 0,
-           hipLaunchKernelGGL(k_bn_fold_bwd, dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, part, m->g + o.w_off,
+           hipLaunchKernelGGL(k_bn_fold_bwd, dim3((C + 7) / 8), dim3(1024), 0, m->stream, C, (int)nb, part, m->g + o.w_off,
                               m->g + o.b_off));
     const size_t n4 = npix * (C / 4);
     const dim3 grid((unsigned)((n4 + 255) / 256));

@@ -137,6 +137,21 @@ struct Model {
     size_t bucket_bytes = 8u << 20;
     int collectives_last_step = 0;       // gradient all-reduce calls issued by the last train step
     int send_bucket(int64_t lo, int64_t hi);
+    // Input pipeline (dnnca_stage_*): a batch travels host -> HBM on its own copy stream into one of a ring of staging slots
+    // while the main stream is still working on the previous step; the main stream waits for the slot's `uploaded` event, runs
+    // the step, sends the step outputs to a pinned host ring and records `done` (the next upload into the slot waits for it,
+    // and the host reads the outputs behind it -- normally one step late, so that it never stalls the launch queue).
+    static constexpr int kStageSlots = 4;
+    struct StageSlot {
+        float *x = nullptr, *y = nullptr;
+        hipEvent_t uploaded = nullptr, done = nullptr;
+        bool has_done = false;           // `done` has been recorded at least once (main thread; handed over with the slot)
+        int batch = 0;
+    } stage[kStageSlots];
+    int stage_slots = 0;
+    size_t stage_bytes = 0;              // capacity of one slot
+    hipStream_t copy_stream = nullptr;
+    float* out_ring = nullptr;           // pinned host memory: kStageSlots x 8 floats (out5 of the step that used the slot)
     // measurement
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int prof_mode = 0;                   // 0 off, 1 every launch, 2 only `focus`, 3 every launch keyed by kernel@layer

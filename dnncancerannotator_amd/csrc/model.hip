@@ -44,6 +44,12 @@ Model::~Model() {
     if (ev_bucket) (void)hipEventDestroy(ev_bucket);
     if (ev_comm_done) (void)hipEventDestroy(ev_comm_done);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    for (auto& sl : stage) {
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (out_ring) (void)hipHostFree(out_ring);
     if (wg_fork) (void)hipEventDestroy(wg_fork);
     if (wg_join) (void)hipEventDestroy(wg_join);
     if (wg_bucket) (void)hipEventDestroy(wg_bucket);
@@ -918,11 +924,17 @@ int dnnca_set_adam(void* model, float beta1, float beta2, float epsilon) {
     return DNNCA_OK;
 }
 
+static int convert_out(Model* M, const float* h, dnnca_step_out* out);
+
 static int read_out(Model* M, dnnca_step_out* out) {
     float h[5];
     HIP_TRY(hipMemcpyAsync(h, M->out5, sizeof(h), hipMemcpyDeviceToHost, M->stream));
     HIP_TRY(hipStreamSynchronize(M->stream));
     DN_TRY(M->flush_profile());
+    return convert_out(M, h, out);
+}
+
+static int convert_out(Model* M, const float* h, dnnca_step_out* out) {
     out->loss = h[0] / (float)M->world;   // after the all-reduce the slot holds the sum over ranks of the local means
     out->positive_rate = h[1];
     out->weight = h[2];
@@ -1010,6 +1022,91 @@ int dnnca_last_step_out(void* model, dnnca_step_out* out) {
     MODEL(model);
     if (!out) return DNNCA_EINVAL;
     return read_out(M, out);
+}
+
+// ---- input pipeline: staging ring + copy stream (model.h) ------------------------------------------------------------------
+static size_t stage_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int dnnca_stage_init(void* model, int slots, size_t bytes_per_slot) {
+    MODEL(model);
+    if (slots < 1 || slots > Model::kStageSlots) { set_error("staging slots %d outside [1, %d]", slots, Model::kStageSlots); return DNNCA_EINVAL; }
+    if (M->stage_slots) { set_error("the staging ring exists already"); return DNNCA_ESTATE; }
+    const size_t xb = (size_t)M->desc.max_batch * M->desc.height * M->desc.width * M->desc.in_channels * 4;
+    const size_t yb = (size_t)M->desc.max_batch * M->outH * M->outW * 4;
+    if (bytes_per_slot < stage_align(xb) + yb) bytes_per_slot = stage_align(xb) + yb;      // at least one float batch (x, y)
+    HIP_TRY(hipStreamCreateWithFlags(&M->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void**)&M->out_ring, (size_t)Model::kStageSlots * 8 * sizeof(float), hipHostMallocDefault));
+    for (int i = 0; i < slots; ++i) {
+        Model::StageSlot& sl = M->stage[i];
+        DN_TRY(M->alloc((void**)&sl.x, stage_align(bytes_per_slot)));
+        HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    M->stage_bytes = stage_align(bytes_per_slot);
+    M->stage_slots = slots;
+    HIP_TRY(hipStreamSynchronize(M->stream));          // the allocations' memsets: nothing of them is left for the copy stream to race
+    return DNNCA_OK;
+}
+
+// May be called from a second host thread (one uploader at a time) while the owning thread enqueues steps: it touches only the
+// slot it was handed, the copy stream and the HIP runtime.  With pageable host memory the call returns when the copy is done;
+// the GPU keeps working on the main stream meanwhile.
+int dnnca_stage_upload(void* model, int slot, const void* host_a, size_t bytes_a, const void* host_b, size_t bytes_b,
+                       void** a_dev, void** b_dev) {
+    MODEL(model);
+    if (slot < 0 || slot >= M->stage_slots) { set_error("staging slot %d outside [0, %d)", slot, M->stage_slots); return DNNCA_EINVAL; }
+    if (stage_align(bytes_a) + bytes_b > M->stage_bytes) {
+        set_error("staging slot holds %zu bytes, asked for %zu + %zu", M->stage_bytes, bytes_a, bytes_b);
+        return DNNCA_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(M->device));                  // the current device is per host thread
+    Model::StageSlot& sl = M->stage[slot];
+    char* base = reinterpret_cast<char*>(sl.x);
+    if (sl.has_done) HIP_TRY(hipStreamWaitEvent(M->copy_stream, sl.done, 0));      // the step that read the slot's last batch
+    if (host_a && bytes_a) HIP_TRY(hipMemcpyAsync(base, host_a, bytes_a, hipMemcpyHostToDevice, M->copy_stream));
+    if (host_b && bytes_b) HIP_TRY(hipMemcpyAsync(base + stage_align(bytes_a), host_b, bytes_b, hipMemcpyHostToDevice, M->copy_stream));
+    HIP_TRY(hipEventRecord(sl.uploaded, M->copy_stream));
+    if (a_dev) *a_dev = base;
+    if (b_dev) *b_dev = base + stage_align(bytes_a);
+    return DNNCA_OK;
+}
+
+int dnnca_stage_uploaded(void* model, int slot) {
+    MODEL(model);
+    if (slot < 0 || slot >= M->stage_slots) { set_error("staging slot %d outside [0, %d)", slot, M->stage_slots); return DNNCA_EINVAL; }
+    HIP_TRY(hipEventSynchronize(M->stage[slot].uploaded));
+    return DNNCA_OK;
+}
+
+int dnnca_stage_wait(void* model, int slot) {
+    MODEL(model);
+    if (slot < 0 || slot >= M->stage_slots) { set_error("staging slot %d outside [0, %d)", slot, M->stage_slots); return DNNCA_EINVAL; }
+    HIP_TRY(hipStreamWaitEvent(M->stream, M->stage[slot].uploaded, 0));
+    return DNNCA_OK;
+}
+
+int dnnca_train_step_staged(void* model, int slot, const float* x_dev, const float* y_dev, int batch, float lr,
+                            const dnnca_loss_cfg* cfg) {
+    MODEL(model);
+    if (slot < 0 || slot >= M->stage_slots) { set_error("staging slot %d outside [0, %d)", slot, M->stage_slots); return DNNCA_EINVAL; }
+    if (batch < 1 || batch > M->desc.max_batch) { set_error("batch %d outside [1, %d]", batch, M->desc.max_batch); return DNNCA_EINVAL; }
+    Model::StageSlot& sl = M->stage[slot];
+    HIP_TRY(hipStreamWaitEvent(M->stream, sl.uploaded, 0));
+    DN_TRY(dnnca_train_step_dev(model, x_dev, y_dev, batch, lr, cfg, nullptr));
+    HIP_TRY(hipMemcpyAsync(M->out_ring + slot * 8, M->out5, 5 * sizeof(float), hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipEventRecord(sl.done, M->stream));
+    sl.has_done = true;
+    sl.batch = batch;
+    return DNNCA_OK;
+}
+
+int dnnca_staged_out(void* model, int slot, dnnca_step_out* out) {
+    MODEL(model);
+    if (!out) return DNNCA_EINVAL;
+    if (slot < 0 || slot >= M->stage_slots || !M->stage[slot].has_done) { set_error("staging slot %d has run no step", slot); return DNNCA_ESTATE; }
+    HIP_TRY(hipEventSynchronize(M->stage[slot].done));
+    if (M->prof_mode) DN_TRY(M->flush_profile());
+    return convert_out(M, M->out_ring + slot * 8, out);
 }
 
 int dnnca_sync(void* model) {

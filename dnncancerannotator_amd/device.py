@@ -94,6 +94,55 @@ class DeviceView:
         return out
 
 
+class StagingRing:
+    """The model's staging slots in HBM + its copy stream (include/dnnca.h, dnnca_stage_*): what ds.prefetch + Keras' asynchronous
+    input feeding are for the reference (annotator/data.py:110,143; engine.py:126-135).  `upload` may run on a second thread."""
+
+    MAX_SLOTS = 4
+
+    def __init__(self, dm, slots=4, slot_bytes=0):
+        self.dm, self.slots = dm, int(slots)
+        check(dm.lib.dnnca_stage_init(dm.handle, self.slots, int(slot_bytes)))
+        x_bytes = dm.max_batch * int(np.prod(dm.in_shape)) * 4
+        y_bytes = dm.max_batch * dm.in_shape[0] * dm.in_shape[1] * 4
+        self.slot_bytes = max(int(slot_bytes), ((x_bytes + 255) & ~255) + y_bytes)
+
+    def fits(self, a, b=None):
+        return ((a.nbytes + 255) & ~255) + (0 if b is None else b.nbytes) <= self.slot_bytes
+
+    def upload(self, slot, a, b=None, wait=True):
+        """host arrays -> the slot, on the copy stream (behind the step that read the slot's previous content); returns the device
+        addresses (c_void_p) of a and b.  wait=True blocks the CALLING thread until the copy has completed, so the arrays may be
+        reused or freed afterwards; with wait=False the caller keeps them alive and unchanged until the slot's step has run."""
+        a = np.ascontiguousarray(a)
+        pa, pb = C.c_void_p(), C.c_void_p()
+        if b is None:
+            check(self.dm.lib.dnnca_stage_upload(self.dm.handle, int(slot), a.ctypes.data_as(C.c_void_p), a.nbytes, None, 0,
+                                                 C.byref(pa), C.byref(pb)))
+            pb = None
+        else:
+            b = np.ascontiguousarray(b)
+            check(self.dm.lib.dnnca_stage_upload(self.dm.handle, int(slot), a.ctypes.data_as(C.c_void_p), a.nbytes,
+                                                 b.ctypes.data_as(C.c_void_p), b.nbytes, C.byref(pa), C.byref(pb)))
+        if wait:
+            check(self.dm.lib.dnnca_stage_uploaded(self.dm.handle, int(slot)))
+        return pa, pb
+
+    def wait(self, slot):
+        """the model's stream waits for the slot's upload (before kernels other than the train step read it)"""
+        check(self.dm.lib.dnnca_stage_wait(self.dm.handle, int(slot)))
+
+    def train_step(self, slot, x_ptr, y_ptr, batch, lr, cfg):
+        """asynchronous train step on device-resident (x, y) that depend on the slot's upload; outputs: out(slot)"""
+        check(self.dm.lib.dnnca_train_step_staged(self.dm.handle, int(slot), x_ptr, y_ptr, int(batch), float(lr), C.byref(cfg)))
+
+    def out(self, slot):
+        """waits for the step that last ran on the slot; raises what train_step would have raised (label / weight assertions)"""
+        out = _lib.StepOut()
+        check(self.dm.lib.dnnca_staged_out(self.dm.handle, int(slot), C.byref(out)))
+        return out
+
+
 class DeviceModel:
     def __init__(self, arch, in_channels, height, width, max_batch, n_filters_first, n_downsample, rate=2, kernel_size=3,
                  conv_stride=1, bn=False, padding='valid', leaky_alpha=0.0, l2=0.0, reference_index=0, n_conv=2,
@@ -265,6 +314,12 @@ class DeviceModel:
     def sync(self):
         check(self.lib.dnnca_sync(self.handle))
 
+    def staging(self, slots=StagingRing.MAX_SLOTS, slot_bytes=0):
+        """the model's StagingRing (created on first use; one per model)"""
+        if getattr(self, '_ring', None) is None:
+            self._ring = StagingRing(self, slots, slot_bytes)
+        return self._ring
+
     def pixel_confusion(self, y, thresholds):
         y = as_f32(y)
         thr = as_f32(thresholds).ravel()
@@ -283,10 +338,12 @@ class DeviceModel:
         return [(c.tp, c.fp, c.fn, c.tn) for c in out]
 
     # ---- device-side augmentation (annotator/data.py:62-111 train_ds) ------------------------------------------
-    def augment_u8(self, raw, params, out_size, label_index, contrast_channels=None):
+    def augment_u8(self, raw, params, out_size, label_index, contrast_channels=None, src_ptr=None):
         """raw uint8 [B, Hs, Ws, Cs] (host) + per-image draws [(dy, dx, flip, contrast)] -> device-resident (x [B, Ho, Wo, Cs-1],
-        y [B, Ho, Wo]) views, valid until the next call.  contrast_channels: source channels to adjust (default: all features)."""
-        raw = np.ascontiguousarray(raw, np.uint8)
+        y [B, Ho, Wo]) views, valid until the next call.  contrast_channels: source channels to adjust (default: all features).
+        src_ptr: the batch is in HBM already (a StagingRing slot; `raw` is then only read for its shape)."""
+        if src_ptr is None:
+            raw = np.ascontiguousarray(raw, np.uint8)
         if raw.ndim != 4:
             raise ValueError('raw batch must be [B, H, W, C] uint8, got %s' % (raw.shape,))
         B, hs, ws, cs = raw.shape
@@ -301,11 +358,13 @@ class DeviceModel:
         if not hasattr(self, '_aug'):
             self._aug = (RawDeviceBuffer(), RawDeviceBuffer(), RawDeviceBuffer())
         src, xb, yb = self._aug
-        src.upload(raw)
+        if src_ptr is None:
+            src.upload(raw)
+            src_ptr = src.ptr
         xb.reserve(B * ho * wo * (cs - 1) * 4)
         yb.reserve(B * ho * wo * 4)
         prm = (_lib.AugParam * B)(*[_lib.AugParam(int(p[0]), int(p[1]), int(p[2]), float(p[3])) for p in params])
-        check(self.lib.dnnca_augment_u8(self.handle, src.ptr, B, hs, ws, cs, int(label_index), mask, prm, ho, wo, xb.ptr, yb.ptr))
+        check(self.lib.dnnca_augment_u8(self.handle, src_ptr, B, hs, ws, cs, int(label_index), mask, prm, ho, wo, xb.ptr, yb.ptr))
         return DeviceView(xb, (B, ho, wo, cs - 1)), DeviceView(yb, (B, ho, wo))
 
     def warp(self, xv, yv, ctrl, wv):

@@ -20,6 +20,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import augment, device, distributed, losses as custom_losses, metrics as custom_metrics, models
+from .feeder import BatchFeeder
 
 
 class History:
@@ -215,53 +216,114 @@ class TFKerasModel:
         results = History(self.model)
         results.params = dict(epochs=max_steps, steps=1, verbose=0)
         best_val, wait = np.inf, 0
-        it = iter(dataset)
+        source = iter(dataset)
         step = self.current_step
         if profile:
             dm.profile_enable(1)
-        t0 = time.time()
-        while max_steps is None or step < max_steps:
+        # Input side (annotator/data.py:110,143 `.prefetch(AUTOTUNE)` + Keras' asynchronous feeding): a BatchFeeder thread draws
+        # the elements, shards them and uploads them into the model's staging slots on a copy stream while the GPU is still on
+        # the previous step; the loop enqueues the step and reads the scalars of the step BEFORE it, so one step is always queued
+        # behind the running one.  Checkpoint / validation steps, the last step and DNNCA_NO_FEEDER=1 read them at once.
+        feeder = None
+        if hasattr(dm, 'staging') and not os.environ.get('DNNCA_NO_FEEDER') and (max_steps is None or step < max_steps):
             try:
-                batch = next(it)
+                first = next(source)
             except StopIteration:
-                logging.warning('dataset exhausted at step %d', step)
-                break
-            if schedule is not None:
-                self.learning_rate = float(schedule(step, self.learning_rate))
-            if isinstance(batch, augment.RawBatch):
-                # uint8 slices + their random draws: crop / flip / contrast / 255 / feature-label split on the device
-                raw, _ = self._shard(batch.raw)
-                params, _ = self._shard(batch.params)
-                xb, yb = dm.augment_u8(raw, params, batch.output_size, batch.label_index)
-                if batch.warp is not None:
-                    xb, yb = dm.warp(xb, yb, self._shard(batch.warp[0])[0], self._shard(batch.warp[1])[0])
-                out = dm.train_step_dev(xb, yb, len(raw), self.learning_rate, cfg, want_out=True)
+                first = None
+            if first is not None:
+                feeder = source = BatchFeeder(dm, source, self._shard, first=first)
             else:
-                x, y = self._shard(np.asarray(batch[0]), np.asarray(batch[1]))
-                out = dm.train_step(x, y, self.learning_rate, cfg)
-            step += 1
-            self.current_step = step
-            logs = dict(loss=float(out.loss), lr=self.learning_rate)
-            if save_path is not None and step % save_freq == 0:
-                self.save(os.path.join(save_path, 'checkpoints', self.ckpt_pattern.format(epoch=step)))
-            if val_data is not None and step % save_freq == 0:
-                val = self._evaluate(val_data)
-                logs.update({'val_' + k: v for k, v in val.items()})
-                if early_stop_steps is not None:
-                    if val['loss'] < best_val:
-                        best_val, wait = val['loss'], 0
-                    else:
-                        wait += 1
-                        if wait >= early_stop_steps:
-                            results.log(step - 1, logs)
-                            logging.warning('early stopping at step %d', step)
-                            break
-            results.log(step - 1, logs)
+                source = iter(())
+        pending = None          # (slot, step, lr) of an enqueued step whose scalars have not been read
+        t0 = time.time()
+
+        def log_step(at, out, lr, extra=None):
+            logs = dict(loss=float(out.loss), lr=lr)
+            if extra:
+                logs.update(extra)
+            results.log(at - 1, logs)
             if log_file is not None:
-                log_file.write('%d,%s\n' % (step, ','.join('%s=%.8g' % kv for kv in logs.items())))
-            if self.ctx.rank == 0 and (step % 100 == 0 or step == max_steps):
-                logging.info('step %d loss %.6f lr %.3g (%.1f steps/s)', step, out.loss, self.learning_rate,
-                             (step - results.epoch[0]) / max(time.time() - t0, 1e-9))
+                log_file.write('%d,%s\n' % (at, ','.join('%s=%.8g' % kv for kv in logs.items())))
+            if self.ctx.rank == 0 and (at % 100 == 0 or at == max_steps):
+                logging.info('step %d loss %.6f lr %.3g (%.1f steps/s)', at, out.loss, lr,
+                             (at - results.epoch[0]) / max(time.time() - t0, 1e-9))
+
+        def read_pending():
+            nonlocal pending
+            if pending is not None:
+                slot_, at, lr = pending
+                pending = None
+                out_ = feeder.ring.out(slot_)       # waits for that step only; raises its label / weight assertions
+                feeder.release(slot_)
+                log_step(at, out_, lr)
+
+        try:
+            while max_steps is None or step < max_steps:
+                try:
+                    item = next(source)
+                except StopIteration:
+                    logging.warning('dataset exhausted at step %d', step)
+                    break
+                if schedule is not None:
+                    self.learning_rate = float(schedule(step, self.learning_rate))
+                if feeder is None:
+                    item = ('host', item)
+                slot, out = None, None
+                if item[0] == 'staged':              # float (x, y), already on its way into a staging slot
+                    _, slot, px, py, n = item
+                    feeder.ring.train_step(slot, px, py, n, self.learning_rate, cfg)
+                elif item[0] == 'raw':               # uint8 source batch in a staging slot: augmentation kernels, then the step
+                    _, slot, src, batch, n = item
+                    feeder.ring.wait(slot)
+                    params, _ = self._shard(batch.params)
+                    xb, yb = dm.augment_u8(self._shard(batch.raw)[0], params, batch.output_size, batch.label_index, src_ptr=src)
+                    if batch.warp is not None:
+                        xb, yb = dm.warp(xb, yb, self._shard(batch.warp[0])[0], self._shard(batch.warp[1])[0])
+                    feeder.ring.train_step(slot, xb.ptr, yb.ptr, n, self.learning_rate, cfg)
+                else:
+                    batch = item[1]
+                    if isinstance(batch, augment.RawBatch):
+                        # uint8 slices + their random draws: crop / flip / contrast / 255 / feature-label split on the device
+                        raw, _ = self._shard(batch.raw)
+                        params, _ = self._shard(batch.params)
+                        xb, yb = dm.augment_u8(raw, params, batch.output_size, batch.label_index)
+                        if batch.warp is not None:
+                            xb, yb = dm.warp(xb, yb, self._shard(batch.warp[0])[0], self._shard(batch.warp[1])[0])
+                        out = dm.train_step_dev(xb, yb, len(raw), self.learning_rate, cfg, want_out=True)
+                    else:
+                        x, y = self._shard(np.asarray(batch[0]), np.asarray(batch[1]))
+                        out = dm.train_step(x, y, self.learning_rate, cfg)
+                step += 1
+                self.current_step = step
+                read_pending()                       # the step before this one (its slot goes back to the feeder)
+                boundary = step % save_freq == 0 and (save_path is not None or val_data is not None)
+                if slot is not None:
+                    if not boundary and (max_steps is None or step < max_steps):
+                        pending = (slot, step, self.learning_rate)
+                        continue
+                    out = feeder.ring.out(slot)
+                    feeder.release(slot)
+                extra = {}
+                if save_path is not None and step % save_freq == 0:
+                    self.save(os.path.join(save_path, 'checkpoints', self.ckpt_pattern.format(epoch=step)))
+                stop = False
+                if val_data is not None and step % save_freq == 0:
+                    val = self._evaluate(val_data)
+                    extra.update({'val_' + k: v for k, v in val.items()})
+                    if early_stop_steps is not None:
+                        if val['loss'] < best_val:
+                            best_val, wait = val['loss'], 0
+                        else:
+                            wait += 1
+                            stop = wait >= early_stop_steps
+                log_step(step, out, self.learning_rate, extra)
+                if stop:
+                    logging.warning('early stopping at step %d', step)
+                    break
+            read_pending()
+        finally:
+            if feeder is not None:
+                feeder.close()
         if log_file is not None:
             log_file.close()
         if profile and save_path is not None and self.ctx.rank == 0:

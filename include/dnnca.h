@@ -160,6 +160,29 @@ int dnnca_forward_dev(void* model, const float* x_dev, int batch, int training);
 int dnnca_last_step_out(void* model, dnnca_step_out* out);        /* synchronises, then reads the last step's scalars */
 int dnnca_sync(void* model);
 
+/* ---- input pipeline: what `ds.prefetch(AUTOTUNE)` (annotator/data.py:110,143) + Keras fit's asynchronous input feeding
+ * (engine.py:126-135) do for the reference.  A ring of `slots` (<= 4) staging slots in HBM and a copy stream: the next
+ * batch travels host -> HBM while the main stream still works on the previous step, and the step outputs come back through a
+ * pinned host ring, so the host never has to wait for the step it has just enqueued.
+ *   dnnca_stage_init           once per model; bytes_per_slot 0 = one float batch (x, y) at max_batch
+ *   dnnca_stage_upload         copies host_a (and host_b right behind it, 256-byte aligned) into the slot on the copy stream, first
+ *                              waiting for the step that consumed the slot's previous content; returns the device addresses.
+ *                              May run on a second host thread (one uploader at a time) beside the thread that enqueues steps.
+ *   dnnca_stage_uploaded       blocks the calling host thread until the slot's upload has completed: the host buffers may then be
+ *                              reused or freed (hipMemcpyAsync from pageable memory gives no such promise on return)
+ *   dnnca_stage_wait           the model's stream waits for the slot's upload (for work other than the step, e.g. dnnca_augment_u8)
+ *   dnnca_train_step_staged    = dnnca_stage_wait + dnnca_train_step_dev(x_dev, y_dev) + outputs to the pinned ring; asynchronous
+ *   dnnca_staged_out           waits for the step that last ran on the slot and reads its scalars (label / weight assertions of
+ *                              utils/losses.py:30,91-92 surface here, i.e. one fetch later than with dnnca_train_step) */
+int dnnca_stage_init(void* model, int slots, size_t bytes_per_slot);
+int dnnca_stage_upload(void* model, int slot, const void* host_a, size_t bytes_a, const void* host_b, size_t bytes_b,
+                       void** a_dev, void** b_dev);
+int dnnca_stage_uploaded(void* model, int slot);
+int dnnca_stage_wait(void* model, int slot);
+int dnnca_train_step_staged(void* model, int slot, const float* x_dev, const float* y_dev, int batch, float lr,
+                            const dnnca_loss_cfg* cfg);
+int dnnca_staged_out(void* model, int slot, dnnca_step_out* out);
+
 /* pixel TP/FP/FN/TN of the last forward/eval probabilities against y at n thresholds (metrics.yaml:2-23 pixel metrics;
  * utils/metrics.py:37-77 FBetaScore builds on them). y_hw is a host buffer [B,H,W]. */
 int dnnca_pixel_confusion(void* model, const float* y_hw, int batch, const float* thresholds, int n, dnnca_confusion* out);

@@ -1,0 +1,223 @@
+"""The input side of the train loop: BatchFeeder (host logic, fake ring) and, -m gpu, the StagingRing / copy-stream path
+against the synchronous host-buffer path it replaces in engine.train (annotator/data.py:110,143 prefetch; engine.py:126-135)."""
+
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from dnncancerannotator_amd import augment
+from dnncancerannotator_amd.feeder import BatchFeeder
+
+UNET = dict(n_filters_first=3, n_downsample=3, rate=2, kernel_size=3, conv_stride=1, bn=False, padding='same')
+
+
+# ---------------------------------------------------------------------------------------------- host logic (no GPU)
+class FakeRing:
+    slots = 3
+
+    def __init__(self, slot_bytes):
+        self.slot_bytes, self.content, self.lock = slot_bytes, {}, threading.Lock()
+
+    def fits(self, a, b=None):
+        return a.nbytes + (0 if b is None else b.nbytes) <= self.slot_bytes
+
+    def upload(self, slot, a, b=None, wait=True):
+        with self.lock:
+            self.content[slot] = (np.array(a), None if b is None else np.array(b))
+        return ('a', slot), ('b', slot)
+
+
+class FakeModel:
+    max_batch = 4
+
+    def __init__(self, slot_bytes=1 << 20):
+        self.ring = FakeRing(slot_bytes)
+
+    def staging(self, slots, slot_bytes):
+        return self.ring
+
+
+def _batches(n, b=2, s=8):
+    rng = np.random.default_rng(0)
+    return [(rng.random((b, s, s, 1), np.float32), (rng.random((b, s, s)) > 0.5).astype(np.float32)) for _ in range(n)]
+
+
+def test_feeder_keeps_order_and_never_overwrites_an_unreleased_slot():
+    dm, data = FakeModel(), _batches(10)
+    f = BatchFeeder(dm, iter(data[1:]), lambda a, b=None: (a, b), first=data[0])
+    held, seen = [], 0
+    for kind, slot, px, py, n in f:
+        assert kind == 'staged' and n == 2 and px == ('a', slot)
+        # the slot's content is this batch, and slots we have not released still hold theirs
+        assert np.array_equal(dm.ring.content[slot][0], data[seen][0])
+        held.append((slot, seen))
+        for s_, i_ in held:
+            assert np.array_equal(dm.ring.content[s_][1], data[i_][1])
+        seen += 1
+        if len(held) == 2:                   # like the train loop: a slot goes back one step late
+            f.release(held.pop(0)[0])
+    assert seen == 10
+    with pytest.raises(StopIteration):
+        next(f)
+    f.close()
+
+
+def test_feeder_shards_falls_back_and_reports_errors():
+    dm = FakeModel(slot_bytes=2 * (8 * 8 + 8 * 8) * 4)          # room for a batch of 2, not of 4
+    small, big = _batches(1, b=2)[0], _batches(1, b=4)[0]
+    shard = lambda a, b=None: (a[:len(a) // 2], None if b is None else b[:len(b) // 2])      # noqa: E731 (rank 0 of 2)
+
+    def gen():
+        yield big                           # its shard (2 images) fits
+        yield (np.concatenate([big[0]] * 4), np.concatenate([big[1]] * 4))      # shard of 8 images: more than a slot and max_batch
+        yield small
+        raise RuntimeError('broken exam')
+
+    f = BatchFeeder(dm, gen(), shard)
+    a = next(f)
+    assert a[0] == 'staged' and a[4] == 2 and np.array_equal(dm.ring.content[a[1]][0], big[0][:2])
+    b = next(f)
+    assert b[0] == 'host' and len(b[1][0]) == 16             # the loop uploads it itself (and shards it itself)
+    c = next(f)
+    assert c[0] == 'staged' and c[4] == 1
+    with pytest.raises(RuntimeError, match='broken exam'):
+        next(f)
+    f.close()
+
+
+def test_feeder_raw_batches_and_close_while_blocked():
+    dm = FakeModel()
+    raw = np.arange(2 * 12 * 12 * 2, dtype=np.uint8).reshape(2, 12, 12, 2)
+    rb = augment.RawBatch(raw, [(0, 0, 0, 1.0)] * 2, (8, 8), 1, None)
+    f = BatchFeeder(dm, iter([rb] * 50), lambda a, b=None: (a, b), first=rb)
+    kind, slot, src, batch, n = next(f)
+    assert kind == 'raw' and n == 2 and batch is rb and np.array_equal(dm.ring.content[slot][0], raw)
+    time.sleep(0.05)                        # the producer now sits on an empty free-slot queue / a full ready queue
+    f.close()
+    assert not f.thread.is_alive()
+
+
+# ---------------------------------------------------------------------------------------------- -m gpu
+def _model(gpu, seed=2, size=32, batch=2):
+    m = gpu.DeviceModel('unet', 1, size, size, batch, **UNET)
+    m.init_glorot(seed=seed)
+    return m
+
+
+def _host_batches(n, size=32, batch=2):
+    from dnncancerannotator_amd.synthetic import synthetic_batch
+    return [synthetic_batch(batch, size, size, 1, seed_x=50 + i, seed_y=70 + i) for i in range(n)]
+
+
+@pytest.mark.gpu
+def test_staging_ring_steps_equal_host_buffer_steps(gpu):
+    data = _host_batches(7)
+    ref, m = _model(gpu), _model(gpu)
+    cfg = ref.loss_cfg(weight_mul=3.0)
+    want = [ref.train_step(x, y, 1e-3, cfg) for x, y in data]
+    ring = m.staging()
+    got, prev = [], None
+    for i, (x, y) in enumerate(data):
+        slot = i % ring.slots
+        px, py = ring.upload(slot, x, y)
+        ring.train_step(slot, px, py, len(x), 1e-3, cfg)
+        if prev is not None:
+            got.append(ring.out(prev))       # one step late: the step just enqueued is still running
+        prev = slot
+    got.append(ring.out(prev))
+    for a, b in zip(want, got):
+        assert abs(a.loss - b.loss) <= 2e-5 * abs(a.loss)
+        assert a.positive_rate == b.positive_rate and a.weight == b.weight and a.label_max == b.label_max
+    pa, pb = ref.get_params(), m.get_params()
+    for name, shape, tr, off in ref.param_infos():
+        if tr:
+            n = int(np.prod(shape))
+            assert np.abs(pa[off:off + n] - pb[off:off + n]).max() <= 1e-4 * max(np.abs(pa[off:off + n]).max(), 1e-3), name
+
+
+@pytest.mark.gpu
+def test_staging_ring_errors_and_late_assertion(gpu):
+    m = _model(gpu)
+    ring = m.staging(slots=2)
+    assert m.staging() is ring                                   # one ring per model
+    cfg = m.loss_cfg(weight_mul=3.0)
+    x = np.zeros((2, 32, 32, 1), np.float32)
+    with pytest.raises(Exception):
+        ring.upload(2, x, x[..., 0])                             # no such slot
+    with pytest.raises(Exception):
+        ring.upload(0, np.zeros((64, 32, 32, 1), np.float32), x[..., 0])      # larger than a slot
+    with pytest.raises(Exception):
+        ring.out(1)                                              # nothing ran on it
+    px, py = ring.upload(0, x, np.full((2, 32, 32), 1.5, np.float32))
+    ring.train_step(0, px, py, 2, 1e-3, cfg)                     # enqueued: the assertion surfaces with the scalars
+    with pytest.raises(Exception) as e:                          # assert_on_max (utils/losses.py:91)
+        ring.out(0)
+    assert 'label outside' in str(e.value)
+    px, py = ring.upload(1, x, np.zeros((2, 32, 32), np.float32))
+    ring.train_step(1, px, py, 2, 1e-3, cfg)
+    out = ring.out(1)
+    assert out.positive_rate == 0.0 and out.weight == 3.0
+
+
+@pytest.mark.gpu
+def test_engine_train_with_feeder_equals_the_synchronous_loop(gpu, tmp_path, monkeypatch):
+    from dnncancerannotator_amd import data, engine
+    config = {'model': 'UNetAnnotator', 'model_options': UNET,
+              'deploy_options': {'optimizer': 'adam', 'loss': {'class_name': 'WeightedCrossentropy', 'config': {'weight_mul': 3.0}},
+                                 'LearningRateScheduler': 'lambda epoch, current_lr: 0.001 * 0.96 ** (epoch // 3)',
+                                 'enable_multigpu': False}}
+
+    def run(tag):
+        ds = data.SyntheticDataset(4, 64, 64, 1, n_batches=3, seed=3)
+        val = data.SyntheticDataset(4, 64, 64, 1, n_batches=1, seed=9, repeat=False)
+        m = engine.TFKerasModel(config)
+        res = m.train(ds, save_path=str(tmp_path / tag), max_steps=11, save_freq=4, val_data=val)
+        return m, res
+
+    m1, r1 = run('feeder')
+    assert getattr(m1.device_model, '_ring', None) is not None            # the staged path really ran
+    monkeypatch.setenv('DNNCA_NO_FEEDER', '1')
+    m2, r2 = run('sync')
+    assert getattr(m2.device_model, '_ring', None) is None
+    assert r1.epoch == r2.epoch == list(range(11))
+    assert np.allclose(r1.history['loss'], r2.history['loss'], rtol=2e-4)
+    assert r1.history['lr'] == r2.history['lr']
+    assert len(r1.history['val_loss']) == len(r2.history['val_loss']) == 2  # steps 4 and 8
+    assert np.allclose(r1.history['val_loss'], r2.history['val_loss'], rtol=2e-4)
+    assert list(m1.get_ckpts(str(tmp_path / 'feeder' / 'checkpoints'))) == [4, 8]
+    assert m1.current_step == m2.current_step == 11
+
+
+@pytest.mark.gpu
+def test_engine_feeder_with_device_side_augmentation(gpu, monkeypatch):
+    """uint8 source batches travel through the staging slots too; same draws -> same losses as the loop that uploads them itself"""
+    from dnncancerannotator_amd import engine
+    config = {'model': 'UNetAnnotator', 'model_options': UNET,
+              'deploy_options': {'optimizer': 'adam', 'loss': {'class_name': 'WeightedCrossentropy', 'config': {'weight_mul': 3.0}},
+                                 'enable_multigpu': False}}
+    rng = np.random.default_rng(5)
+    raws = []
+    for _ in range(5):
+        raw = rng.integers(0, 256, size=(2, 44, 44, 2), dtype=np.uint8)
+        raw[..., 1] = (raw[..., 1] > 200).astype(np.uint8) * 255           # label channel: 0 / 255
+        params = [(int(rng.integers(-6, 7)), int(rng.integers(-6, 7)), int(rng.integers(0, 2)), float(rng.uniform(0.8, 1.2)))
+                  for _ in range(2)]
+        raws.append(augment.RawBatch(raw, params, (32, 32), 1, None))
+
+    class DS:
+        element_spec = None
+
+        def __iter__(self):
+            return iter(raws)
+
+    def run():
+        m = engine.TFKerasModel(config)
+        m._build([(np.zeros((2, 32, 32, 1), np.float32), np.zeros((2, 32, 32), np.float32))])
+        return m.train(DS(), max_steps=5).history['loss']
+
+    a = run()
+    monkeypatch.setenv('DNNCA_NO_FEEDER', '1')
+    b = run()
+    assert len(a) == len(b) == 5 and np.allclose(a, b, rtol=2e-4)
