@@ -97,6 +97,9 @@ SIGNATURES = {
     'dnnca_stage_wait': (C.c_int, [_VP, C.c_int]),
     'dnnca_train_step_staged': (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int, C.c_float, C.POINTER(LossCfg)]),
     'dnnca_staged_out': (C.c_int, [_VP, C.c_int, C.POINTER(StepOut)]),
+    'dnnca_eval_begin': (C.c_int, [_VP, _VP, C.c_int]),
+    'dnnca_eval_step_staged': (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int, C.POINTER(LossCfg)]),
+    'dnnca_eval_end': (C.c_int, [_VP, C.POINTER(Confusion)]),
     'dnnca_pixel_confusion': (C.c_int, [_VP, _FP, C.c_int, _FP, C.c_int, C.POINTER(Confusion)]),
     'dnnca_pixel_confusion_of': (C.c_int, [_VP, _FP, _FP, C.c_int64, _FP, C.c_int, C.POINTER(Confusion)]),
     'dnnca_comm_unique_id': (C.c_int, [_VP]),

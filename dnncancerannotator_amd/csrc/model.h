@@ -146,11 +146,16 @@ struct Model {
         float *x = nullptr, *y = nullptr;
         hipEvent_t uploaded = nullptr, done = nullptr;
         bool has_done = false;           // `done` has been recorded at least once (main thread; handed over with the slot)
+        bool is_eval = false;            // the step that last ran on the slot was an evaluation step (rank-local loss)
         int batch = 0;
     } stage[kStageSlots];
     int stage_slots = 0;
     size_t stage_bytes = 0;              // capacity of one slot
     hipStream_t copy_stream = nullptr;
+    // staged evaluation (dnnca_eval_begin .. dnnca_eval_end): the pixel-confusion histogram stays on the device and keeps adding
+    // up over the batches (exact integer counts); it is read once, at the end
+    bool eval_active = false;
+    std::vector<int> eval_order;         // thresholds: sorted position -> the caller's position
     float* out_ring = nullptr;           // pinned host memory: kStageSlots x 8 floats (out5 of the step that used the slot)
     // measurement
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -925,6 +925,8 @@ int dnnca_set_adam(void* model, float beta1, float beta2, float epsilon) {
 }
 
 static int convert_out(Model* M, const float* h, dnnca_step_out* out);
+static int confusion_begin(Model* M, const float* thresholds, int n, std::vector<int>& order);
+static int confusion_finish(Model* M, int n, const std::vector<int>& order, dnnca_confusion* out);
 
 static int read_out(Model* M, dnnca_step_out* out) {
     float h[5];
@@ -1096,6 +1098,7 @@ int dnnca_train_step_staged(void* model, int slot, const float* x_dev, const flo
     HIP_TRY(hipMemcpyAsync(M->out_ring + slot * 8, M->out5, 5 * sizeof(float), hipMemcpyDeviceToHost, M->stream));
     HIP_TRY(hipEventRecord(sl.done, M->stream));
     sl.has_done = true;
+    sl.is_eval = false;
     sl.batch = batch;
     return DNNCA_OK;
 }
@@ -1106,7 +1109,55 @@ int dnnca_staged_out(void* model, int slot, dnnca_step_out* out) {
     if (slot < 0 || slot >= M->stage_slots || !M->stage[slot].has_done) { set_error("staging slot %d has run no step", slot); return DNNCA_ESTATE; }
     HIP_TRY(hipEventSynchronize(M->stage[slot].done));
     if (M->prof_mode) DN_TRY(M->flush_profile());
-    return convert_out(M, M->out_ring + slot * 8, out);
+    const int world = M->world;
+    if (M->stage[slot].is_eval) M->world = 1;      // evaluation is rank-local: the loss slot was not all-reduced
+    const int rc = convert_out(M, M->out_ring + slot * 8, out);
+    M->world = world;
+    return rc;
+}
+
+// ---- staged evaluation: keras Model.evaluate (engine.py:198-203) over the staging ring ---------------------------------
+int dnnca_eval_begin(void* model, const float* thresholds, int n) {
+    MODEL(model);
+    if (n < 0 || n > DNNCA_CONF_MAX_THR || (n > 0 && !thresholds)) { set_error("bad thresholds (0..%d)", DNNCA_CONF_MAX_THR); return DNNCA_EINVAL; }
+    if (!M->stage_slots) { set_error("dnnca_eval_begin before dnnca_stage_init"); return DNNCA_ESTATE; }
+    M->eval_order.clear();
+    if (n > 0) DN_TRY(confusion_begin(M, thresholds, n, M->eval_order));
+    M->eval_active = true;
+    return DNNCA_OK;
+}
+
+int dnnca_eval_step_staged(void* model, int slot, const float* x_dev, const float* y_dev, int batch, const dnnca_loss_cfg* cfg) {
+    MODEL(model);
+    if (!M->eval_active) { set_error("dnnca_eval_step_staged outside dnnca_eval_begin .. dnnca_eval_end"); return DNNCA_ESTATE; }
+    if (!cfg) { set_error("null loss cfg"); return DNNCA_EINVAL; }
+    if (slot < 0 || slot >= M->stage_slots) { set_error("staging slot %d outside [0, %d)", slot, M->stage_slots); return DNNCA_EINVAL; }
+    if (batch < 1 || batch > M->desc.max_batch) { set_error("batch %d outside [1, %d]", batch, M->desc.max_batch); return DNNCA_EINVAL; }
+    Model::StageSlot& sl = M->stage[slot];
+    HIP_TRY(hipStreamWaitEvent(M->stream, sl.uploaded, 0));
+    DN_TRY(M->forward(x_dev, batch, false));
+    DN_TRY(M->loss_and_backward(y_dev, batch, *cfg, false));
+    const int n = (int)M->eval_order.size();
+    if (n > 0)      // the metrics see the labels as given (a smoothed copy exists only inside the loss, utils/losses.py:62-67)
+        g_confusion_hist(M->stream, (size_t)batch * M->outH * M->outW, M->prob, y_dev, M->thr_dev, n,
+                         reinterpret_cast<unsigned long long*>(M->conf_dev));
+    HIP_TRY(hipMemcpyAsync(M->out_ring + slot * 8, M->out5, 5 * sizeof(float), hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipEventRecord(sl.done, M->stream));
+    sl.has_done = true;
+    sl.is_eval = true;
+    sl.batch = batch;
+    return DNNCA_OK;
+}
+
+int dnnca_eval_end(void* model, dnnca_confusion* out) {
+    MODEL(model);
+    if (!M->eval_active) { set_error("dnnca_eval_end without dnnca_eval_begin"); return DNNCA_ESTATE; }
+    M->eval_active = false;
+    const int n = (int)M->eval_order.size();
+    if (n > 0 && !out) { set_error("null confusion output"); return DNNCA_EINVAL; }
+    if (n > 0) return confusion_finish(M, n, M->eval_order, out);
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    return DNNCA_OK;
 }
 
 int dnnca_sync(void* model) {
@@ -1124,9 +1175,9 @@ int dnnca_dev_free(void* dev_ptr) { HIP_TRY(hipFree(dev_ptr)); return DNNCA_OK; 
 int dnnca_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) { HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice)); return DNNCA_OK; }
 int dnnca_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) { HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost)); return DNNCA_OK; }
 
-static int confusion_counts(Model* M, size_t npix, const float* thresholds, int n, dnnca_confusion* out) {
-    // sort the thresholds (stable order of the caller is restored below); the kernel wants them ascending
-    std::vector<int> order(n);
+// thresholds -> ascending on the device (the histogram kernel wants them sorted), histogram zeroed; order[t] = caller's position
+static int confusion_begin(Model* M, const float* thresholds, int n, std::vector<int>& order) {
+    order.resize(n);
     for (int i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return thresholds[a] < thresholds[b]; });
     std::vector<float> sorted(n);
@@ -1134,13 +1185,17 @@ static int confusion_counts(Model* M, size_t npix, const float* thresholds, int 
         sorted[i] = thresholds[order[i]];
         if (sorted[i] != sorted[i]) { set_error("threshold %d is NaN", order[i]); return DNNCA_EINVAL; }
     }
-    unsigned long long* hist = reinterpret_cast<unsigned long long*>(M->conf_dev);
-    size_t hbytes = (size_t)2 * (n + 1) * 8;
     HIP_TRY(hipMemcpyAsync(M->thr_dev, sorted.data(), (size_t)n * 4, hipMemcpyHostToDevice, M->stream));
-    HIP_TRY(hipMemsetAsync(hist, 0, hbytes, M->stream));
-    g_confusion_hist(M->stream, npix, M->prob, M->y_stage, M->thr_dev, n, hist);
+    HIP_TRY(hipMemsetAsync(M->conf_dev, 0, (size_t)2 * (n + 1) * 8, M->stream));
+    HIP_TRY(hipStreamSynchronize(M->stream));          // `sorted` is a local
+    return DNNCA_OK;
+}
+
+// histogram [positives | negatives][n + 1 bins] -> TP / FP / FN / TN per threshold, in the caller's order
+static int confusion_finish(Model* M, int n, const std::vector<int>& order, dnnca_confusion* out) {
+    const size_t hbytes = (size_t)2 * (n + 1) * 8;
     std::vector<unsigned long long> h((size_t)2 * (n + 1));
-    HIP_TRY(hipMemcpyAsync(h.data(), hist, hbytes, hipMemcpyDeviceToHost, M->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), M->conf_dev, hbytes, hipMemcpyDeviceToHost, M->stream));
     HIP_TRY(hipStreamSynchronize(M->stream));
     const unsigned long long* pos = h.data();
     const unsigned long long* neg = h.data() + (n + 1);
@@ -1157,6 +1212,13 @@ static int confusion_counts(Model* M, size_t npix, const float* thresholds, int 
         o.tn = (double)(N - fp);
     }
     return DNNCA_OK;
+}
+
+static int confusion_counts(Model* M, size_t npix, const float* thresholds, int n, dnnca_confusion* out) {
+    std::vector<int> order;
+    DN_TRY(confusion_begin(M, thresholds, n, order));
+    g_confusion_hist(M->stream, npix, M->prob, M->y_stage, M->thr_dev, n, reinterpret_cast<unsigned long long*>(M->conf_dev));
+    return confusion_finish(M, n, order, out);
 }
 
 int dnnca_pixel_confusion(void* model, const float* y_hw, int batch, const float* thresholds, int n, dnnca_confusion* out) {

@@ -136,6 +136,21 @@ class StagingRing:
         """asynchronous train step on device-resident (x, y) that depend on the slot's upload; outputs: out(slot)"""
         check(self.dm.lib.dnnca_train_step_staged(self.dm.handle, int(slot), x_ptr, y_ptr, int(batch), float(lr), C.byref(cfg)))
 
+    # keras Model.evaluate (engine.py:198-203) over the ring: the confusion histogram of ALL thresholds stays on the device
+    def eval_begin(self, thresholds=()):
+        thr = as_f32(np.asarray(thresholds, np.float32)).ravel()
+        self._n_thr = int(thr.size)
+        check(self.dm.lib.dnnca_eval_begin(self.dm.handle, thr.ctypes.data_as(C.c_void_p) if thr.size else None, self._n_thr))
+
+    def eval_step(self, slot, x_ptr, y_ptr, batch, cfg):
+        check(self.dm.lib.dnnca_eval_step_staged(self.dm.handle, int(slot), x_ptr, y_ptr, int(batch), C.byref(cfg)))
+
+    def eval_end(self):
+        """[(tp, fp, fn, tn)] per threshold of eval_begin, summed over every eval_step since (exact integers)"""
+        out = (_lib.Confusion * max(self._n_thr, 1))()
+        check(self.dm.lib.dnnca_eval_end(self.dm.handle, out))
+        return [(c.tp, c.fp, c.fn, c.tn) for c in out[:self._n_thr]]
+
     def out(self, slot):
         """waits for the step that last ran on the slot; raises what train_step would have raised (label / weight assertions)"""
         out = _lib.StepOut()

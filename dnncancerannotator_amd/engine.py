@@ -333,7 +333,7 @@ class TFKerasModel:
         return results
 
     # ---- evaluation (engine.py:139-210) ----------------------------------------------------------------------
-    def _evaluate(self, dataset):
+    def _evaluate(self, dataset, staged=False):
         """keras Model.evaluate(return_dict=True): mean loss over batches + pixel metrics, training=False.  One batch of
         the dataset is one test step per replica: the positive-rate class weight (utils/losses.py:24-27) is taken over the
         whole per-replica batch, never over a chunk of it."""
@@ -341,6 +341,8 @@ class TFKerasModel:
         for m in self.metrics:
             m.reset_state()
         total, count = 0.0, 0
+        if staged and self._staged_eval_possible():
+            total, count, dataset = self._evaluate_staged(dataset, cfg_kw)      # what is left: batches the ring could not take
         for x, y in dataset:
             x, y = self._shard(np.asarray(x), np.asarray(y))
             if len(x):
@@ -380,6 +382,54 @@ class TFKerasModel:
             results[m.name] = float(r) if np.ndim(r) == 0 else [float(v) for v in r]
         return results
 
+    def _staged_eval_possible(self):
+        n_thr = sum(len(m.thresholds) for m in self.metrics)
+        return (hasattr(self.device_model, 'staging') and not os.environ.get('DNNCA_NO_FEEDER') and n_thr <= 1024 and
+                all(hasattr(m, 'thresholds') and hasattr(m, 'counts') for m in self.metrics))
+
+    def _evaluate_staged(self, dataset, cfg_kw):
+        """The test steps of _evaluate over the staging ring (feeder.py): batches travel to HBM on the copy stream while the
+        previous one is evaluated, every metric's thresholds share ONE confusion histogram that stays on the device and is read
+        once at the end (exact integer counts), and a batch's loss is read one step late.  Returns (loss sum, sample count,
+        the batches the ring could not take -- larger than max_batch -- for the chunked path)."""
+        dm = self.device_model
+        source = iter(dataset)
+        try:
+            first = next(source)
+        except StopIteration:
+            return 0.0, 0, []
+        self._ensure_capacity(len(self._shard(np.asarray(first[0]))[0]))
+        dm = self.device_model
+        feeder = BatchFeeder(dm, source, self._shard, first=first)
+        ring = feeder.ring
+        thr = np.concatenate([m.thresholds for m in self.metrics]) if self.metrics else np.zeros(0, np.float32)
+        cfg = dm.loss_cfg(**cfg_kw)
+        total, count, left, pending = 0.0, 0, [], None
+        ring.eval_begin(thr)
+        try:
+            for item in feeder:
+                if item[0] != 'staged':
+                    left.append(item[1])
+                    continue
+                _, slot, px, py, n = item
+                ring.eval_step(slot, px, py, n, cfg)
+                if pending is not None:
+                    total += float(ring.out(pending[0]).loss) * pending[1]
+                    count += pending[1]
+                    feeder.release(pending[0])
+                pending = (slot, n)
+            if pending is not None:
+                total += float(ring.out(pending[0]).loss) * pending[1]
+                count += pending[1]
+        finally:
+            feeder.close()
+            counts = np.asarray(ring.eval_end(), np.float64).reshape(-1, 4)
+        lo = 0
+        for m in self.metrics:
+            m.counts += counts[lo:lo + len(m.thresholds)]
+            lo += len(m.thresholds)
+        return total, count, left
+
     def eval(self, dataset, save_path, viz_ds=None, tag='val', avoid_overwrite=False, export_path=None, export_images=False,
              visualize_sensitivity=False, export_csv=False, min_interval=1, step_range=None, overlay=False,
              export_casewise_metrics=False):
@@ -410,7 +460,7 @@ class TFKerasModel:
                 continue
             previous_step = ckpt_step
             self.load(ckpt_path_)
-            rows[ckpt_step] = self._evaluate(dataset)
+            rows[ckpt_step] = self._evaluate(dataset, staged=True)
         if export_csv and self.ctx.rank == 0:
             os.makedirs(os.path.join(export_path, tag), exist_ok=True)
             with open(os.path.join(export_path, tag, 'results.csv'), 'w') as f:

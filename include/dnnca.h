@@ -182,6 +182,13 @@ int dnnca_stage_wait(void* model, int slot);
 int dnnca_train_step_staged(void* model, int slot, const float* x_dev, const float* y_dev, int batch, float lr,
                             const dnnca_loss_cfg* cfg);
 int dnnca_staged_out(void* model, int slot, dnnca_step_out* out);
+/* keras Model.evaluate (engine.py:198-203) over the staging ring: test steps (forward with training=False + loss) on staged
+ * batches; the pixel TP/FP/FN/TN histogram of the n thresholds (all metrics' thresholds at once, any order, n may be 0) stays
+ * on the device and keeps adding up over the batches -- exact integer counts, read once by dnnca_eval_end.  Per-batch losses come
+ * back through dnnca_staged_out (rank-local, like dnnca_eval_step).  dnnca_pixel_confusion* must not be called in between. */
+int dnnca_eval_begin(void* model, const float* thresholds, int n);
+int dnnca_eval_step_staged(void* model, int slot, const float* x_dev, const float* y_dev, int batch, const dnnca_loss_cfg* cfg);
+int dnnca_eval_end(void* model, dnnca_confusion* out /* n entries, the caller's threshold order */);
 
 /* pixel TP/FP/FN/TN of the last forward/eval probabilities against y at n thresholds (metrics.yaml:2-23 pixel metrics;
  * utils/metrics.py:37-77 FBetaScore builds on them). y_hw is a host buffer [B,H,W]. */

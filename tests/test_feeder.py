@@ -221,3 +221,38 @@ def test_engine_feeder_with_device_side_augmentation(gpu, monkeypatch):
     monkeypatch.setenv('DNNCA_NO_FEEDER', '1')
     b = run()
     assert len(a) == len(b) == 5 and np.allclose(a, b, rtol=2e-4)
+
+
+@pytest.mark.gpu
+def test_engine_eval_over_the_staging_ring_equals_the_per_batch_path(gpu, tmp_path, monkeypatch):
+    """`annotator evaluate`: test steps on staged batches, ONE device-resident confusion histogram for all metrics (302
+    thresholds of configs/additionals/metrics.yaml:2-23), losses read one step late -- same rows as the per-batch path"""
+    from dnncancerannotator_amd import data, engine
+    config = {'model': 'UNetAnnotator', 'model_options': UNET,
+              'deploy_options': {'optimizer': 'adam', 'loss': {'class_name': 'WeightedCrossentropy', 'config': {'weight_mul': 3.0}},
+                                 'enable_multigpu': False,
+                                 'metrics': [{'Precision': {'thresholds': 0.8, 'name': 'pixel/precision'}},
+                                             {'Recall': {'thresholds': 0.8, 'name': 'pixel/recall'}},
+                                             {'AUC': {'curve': 'PR', 'name': 'pixel/AUPRC', 'num_thresholds': 150}},
+                                             {'AUC': {'curve': 'ROC', 'name': 'pixel/AUROC', 'num_thresholds': 150}},
+                                             {'FBetaScore': {'thresholds': 0.8, 'beta': 1.0, 'name': 'pixel/F1-score'}},
+                                             {'FBetaScore': {'thresholds': 0.5, 'beta': 2.0, 'name': 'pixel/F2-score'}}]}}
+    save = str(tmp_path / 'run')
+    m = engine.TFKerasModel(config)
+    m.train(data.SyntheticDataset(4, 64, 64, 1, n_batches=2, seed=3), save_path=save, max_steps=12, save_freq=6)
+    # 5 batches of 4 and a last one of 2 (a remainder batch is a smaller test step)
+    xs, ys = zip(*[_host_batches(1, size=64, batch=4)[0] for _ in range(5)])
+    x, y = np.concatenate(xs)[:18], np.concatenate(ys)[:18]
+    x[4:] = np.random.default_rng(1).random(x[4:].shape, np.float32)
+    ev = data.ArrayDataset(x, y, 4)
+    rows_a = engine.TFKerasModel(config).eval(ev, save_path=save, tag='staged')
+    monkeypatch.setenv('DNNCA_NO_FEEDER', '1')
+    rows_b = engine.TFKerasModel(config).eval(ev, save_path=save, tag='per_batch')
+    assert list(rows_a) == list(rows_b) == [6, 12]
+    for step in rows_a:
+        a, b = rows_a[step], rows_b[step]
+        assert set(a) == set(b) and len(a) == 7
+        assert abs(a['loss'] - b['loss']) <= 1e-6 * abs(b['loss'])
+        for k in a:
+            if k != 'loss':
+                assert a[k] == b[k], (step, k)        # integer counts: the metrics are identical

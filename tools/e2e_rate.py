@@ -107,3 +107,22 @@ eng.train(Gen(20), max_steps=20, auto_resume=False)
 t0 = time.perf_counter()
 eng.train(Gen(N), max_steps=20 + N, auto_resume=False)
 report('engine', time.perf_counter() - t0)
+
+
+# `annotator evaluate`: keras Model.evaluate with the pixel metrics of configs/additionals/metrics.yaml (302 thresholds)
+config['deploy_options']['metrics'] = [{'Precision': {'thresholds': 0.8, 'name': 'pixel/precision'}},
+                                       {'Recall': {'thresholds': 0.8, 'name': 'pixel/recall'}},
+                                       {'AUC': {'curve': 'PR', 'name': 'pixel/AUPRC', 'num_thresholds': 150}},
+                                       {'AUC': {'curve': 'ROC', 'name': 'pixel/AUROC', 'num_thresholds': 150}},
+                                       {'FBetaScore': {'thresholds': 0.8, 'beta': 1.0, 'name': 'pixel/F1-score'}},
+                                       {'FBetaScore': {'thresholds': 0.8, 'beta': 2.0, 'name': 'pixel/F2-score'}}]
+ev = TFKerasModel(config)
+ev._build(Gen(1))
+NE = max(N // 4, 8)
+ev._evaluate(Gen(4), staged=True)
+for staged in (False, True):
+    t0 = time.perf_counter()
+    r = ev._evaluate(Gen(NE), staged=staged)
+    dt = time.perf_counter() - t0
+    print('%-10s %8.3f ms/batch %9.1f slices/s (loss %.6f, F1 %.6f)' % ('eval' + ('-ring' if staged else '-sync'), dt / NE * 1e3, B * NE / dt,
+                                                                      r['loss'], r['pixel/F1-score']), flush=True)
