@@ -18,6 +18,32 @@ import numpy as np
 AugmentPlan = namedtuple('AugmentPlan', ['crop', 'flip', 'contrast', 'warp', 'output_size'])
 RawBatch = namedtuple('RawBatch', ['raw', 'params', 'output_size', 'label_index', 'warp'])      # warp: (ctrl, wv) or None
 
+
+
+def plain_params(n):
+    """the draws of a batch that is only converted (evaluation: centre crop, no flip, no contrast)"""
+    return [(0, 0, 0, 1.0)] * n
+
+
+def raw_to_float(batch):
+    """Host statement of what the device does with an un-augmented RawBatch (params None): centre crop to output_size, / 255,
+    label channel -> y, the other channels -> x (annotator/data.py:195-206,766-788).  For consumers without the device path."""
+    if batch.params is not None:
+        raise ValueError('raw_to_float converts evaluation batches only (no random draws)')
+    raw = np.asarray(batch.raw)
+    oh, ow = batch.output_size
+    gy, gx = (raw.shape[1] - oh) // 2, (raw.shape[2] - ow) // 2
+    c = raw[:, gy:gy + oh, gx:gx + ow, :]
+    feat = [i for i in range(raw.shape[-1]) if i != batch.label_index]
+    x = np.empty(c.shape[:-1] + (len(feat),), np.float32)
+    for j, i in enumerate(feat):
+        x[..., j] = c[..., i]
+    np.divide(x, np.float32(255.0), out=x)
+    y = c[..., batch.label_index].astype(np.float32)
+    np.divide(y, np.float32(255.0), out=y)
+    return x, y
+
+
 _KNOWN = ('random_crop', 'random_flip', 'random_contrast', 'random_warp')
 _warned = set()
 

@@ -343,7 +343,8 @@ class TFKerasModel:
         total, count = 0.0, 0
         if staged and self._staged_eval_possible():
             total, count, dataset = self._evaluate_staged(dataset, cfg_kw)      # what is left: batches the ring could not take
-        for x, y in dataset:
+        for el in dataset:
+            x, y = augment.raw_to_float(el) if isinstance(el, augment.RawBatch) else el
             x, y = self._shard(np.asarray(x), np.asarray(y))
             if len(x):
                 self._ensure_capacity(len(x))
@@ -398,7 +399,7 @@ class TFKerasModel:
             first = next(source)
         except StopIteration:
             return 0.0, 0, []
-        self._ensure_capacity(len(self._shard(np.asarray(first[0]))[0]))
+        self._ensure_capacity(len(self._shard(np.asarray(first.raw if isinstance(first, augment.RawBatch) else first[0]))[0]))
         dm = self.device_model
         feeder = BatchFeeder(dm, source, self._shard, first=first)
         ring = feeder.ring
@@ -408,10 +409,17 @@ class TFKerasModel:
         ring.eval_begin(thr)
         try:
             for item in feeder:
-                if item[0] != 'staged':
+                if item[0] == 'host':
                     left.append(item[1])
                     continue
-                _, slot, px, py, n = item
+                if item[0] == 'raw':         # uint8 slices in the slot: centre crop, / 255 and the feature-label split on the device
+                    _, slot, src, batch, n = item
+                    ring.wait(slot)
+                    xv, yv = dm.augment_u8(self._shard(batch.raw)[0], augment.plain_params(n), batch.output_size, batch.label_index,
+                                           contrast_channels=(), src_ptr=src)
+                    px, py = xv.ptr, yv.ptr
+                else:
+                    _, slot, px, py, n = item
                 ring.eval_step(slot, px, py, n, cfg)
                 if pending is not None:
                     total += float(ring.out(pending[0]).loss) * pending[1]

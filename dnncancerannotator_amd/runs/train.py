@@ -27,6 +27,7 @@ def make_dataset(paths, options, training):
                                repeat=training, drop_remainder=training,
                                augment_options=options.get('augment_options') if training else False,
                                buffer_size=options.get('buffer_size', 0) if training else 0,
+                               device_convert=not training,      # evaluation: uint8 to the device, / 255 and the split there
                                normalize_exams=bool(options.get('normalize_exams', True)) if training else False)   # data.py:68,137
     if all(p.endswith('.npz') for p in paths):
         import numpy as np

@@ -11,6 +11,7 @@ Formats implemented from their public specifications: TFRecord framing (length, 
 protobuf wire format (varint / 64-bit / length-delimited / 32-bit), tensorflow/core/example/{example,feature}.proto and
 tensorflow/core/framework/{tensor,tensor_shape}.proto field numbers.  No file of the reference ships with the repo."""
 
+import os
 import struct
 from collections import namedtuple
 
@@ -49,25 +50,31 @@ def masked_crc(data):
 
 # ------------------------------------------------------------------------------------------------ TFRecord framing
 def read_records(path, verify_payload_crc=False):
-    """Yields the payload of every record.  The 12-byte header CRC is always checked; the payload CRC (a pure-Python
-    loop over megabytes of pixels) only on request."""
+    """Yields the payload of every record as a memoryview into a read-only mapping of the file (no copy: an exam's pixels go from
+    the page cache straight into whoever picks them apart).  The 12-byte header CRC is always checked; the payload CRC (a
+    pure-Python loop over megabytes of pixels) only on request."""
+    import mmap
+    size = os.path.getsize(path)
+    if size == 0:
+        return
     with open(path, 'rb') as f:
-        while True:
-            header = f.read(12)
-            if not header:
-                return
-            if len(header) < 12:
-                raise IOError('truncated TFRecord header in %s' % path)
-            length, = struct.unpack('<Q', header[:8])
-            if struct.unpack('<I', header[8:])[0] != masked_crc(header[:8]):
-                raise IOError('corrupt TFRecord length CRC in %s' % path)
-            data = f.read(length)
-            footer = f.read(4)
-            if len(data) < length or len(footer) < 4:
-                raise IOError('truncated TFRecord payload in %s' % path)
-            if verify_payload_crc and struct.unpack('<I', footer)[0] != masked_crc(data):
-                raise IOError('corrupt TFRecord payload CRC in %s' % path)
-            yield data
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)      # stays alive as long as a payload view does
+    buf = memoryview(mm)
+    pos = 0
+    while pos < size:
+        if size - pos < 12:
+            raise IOError('truncated TFRecord header in %s' % path)
+        header = bytes(buf[pos:pos + 12])
+        length, = struct.unpack('<Q', header[:8])
+        if struct.unpack('<I', header[8:])[0] != masked_crc(header[:8]):
+            raise IOError('corrupt TFRecord length CRC in %s' % path)
+        if size - pos - 12 < length + 4:
+            raise IOError('truncated TFRecord payload in %s' % path)
+        data = buf[pos + 12:pos + 12 + length]
+        if verify_payload_crc and struct.unpack('<I', bytes(buf[pos + 12 + length:pos + 16 + length]))[0] != masked_crc(data):
+            raise IOError('corrupt TFRecord payload CRC in %s' % path)
+        pos += 16 + length
+        yield data
 
 
 def write_records(path, payloads):
@@ -150,8 +157,8 @@ def parse_example(data):
                 for vnum, vwt, v in _fields(lst):
                     if vnum != 1:
                         continue
-                    if knum == 1:                           # BytesList
-                        values.append(bytes(v))
+                    if knum == 1:                           # BytesList (a serialized tensor stays a view: megabytes of pixels)
+                        values.append(v if len(v) > 4096 else bytes(v))
                     elif knum == 3:                         # Int64List (packed or not)
                         if vwt == 2:
                             pos, raw = 0, bytes(v)
@@ -231,8 +238,36 @@ def read_exams(path, output_slice_types=None):
         types = [t.decode() for t in ex['slice_types']]
         if output_slice_types is not None:
             idx = [types.index(t) for t in output_slice_types]
-            slices, types = slices[..., idx], list(output_slice_types)
+            if idx != list(range(slices.shape[-1])):
+                # channel by channel into a C-ordered array (`slices[..., idx]` would come back with the channel axis outermost in
+                # memory: every later pass over it -- crop, cast, stack -- then crawls)
+                picked = np.empty(slices.shape[:-1] + (len(idx),), np.uint8)
+                for j, i in enumerate(idx):
+                    picked[..., j] = slices[..., i]
+                slices = picked
+            types = list(output_slice_types)
         yield Exam(slices, ex['patientID'][0], ex['examID'][0], ex['path'][0].decode(), ex['category'][0].decode(), types)
+
+
+def read_exams_parallel(paths, output_slice_types=None, workers=None):
+    """[exams of paths[0]], [exams of paths[1]], ... in order, with up to `workers` files being read and decoded ahead on threads --
+    what `interleave(..., num_parallel_calls=AUTOTUNE)` / the parallel maps of annotator/data.py:178,283,294 do for the
+    reference.  File reads, the big byte copies and the channel picks all release the GIL."""
+    paths = list(paths)
+    if workers is None:
+        workers = min(8, max(1, (os.cpu_count() or 2) // 2))
+    if workers <= 1 or len(paths) <= 1:
+        for p in paths:
+            yield list(read_exams(p, output_slice_types))
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers, thread_name_prefix='dnnca-exam-reader') as pool:
+        pending, nxt = [], 0
+        while pending or nxt < len(paths):
+            while nxt < len(paths) and len(pending) < workers + 1:
+                pending.append(pool.submit(lambda q: list(read_exams(q, output_slice_types)), paths[nxt]))
+                nxt += 1
+            yield pending.pop(0).result()
 
 
 class TFRecordDataset:
@@ -248,7 +283,8 @@ class TFRecordDataset:
     device (`dnnca_augment_u8` / `dnnca_warp_f32`, engine.train)."""
 
     def __init__(self, paths, slice_types, batch_size, output_size=(512, 512), repeat=False, drop_remainder=False,
-                 augment_options=False, buffer_size=0, seed=0, normalize_exams=False, **ignored):
+                 augment_options=False, buffer_size=0, seed=0, normalize_exams=False, device_convert=False, workers=None,
+                 **ignored):
         from . import augment
         self.paths = list(paths)
         self.slice_types = list(slice_types)
@@ -261,6 +297,11 @@ class TFRecordDataset:
         if self.plan is not None:
             self.output_size = self.plan.output_size
         self.buffer_size = int(buffer_size)
+        self.workers = workers                # reader threads (None: half the cores, at most eight)
+        # evaluation with device_convert: the centre-cropped uint8 slices travel as `augment.RawBatch`es without draws (params None)
+        # -- a quarter of the float bytes over PCIe, no float copy of an exam on the host; the engine converts them on the device
+        # (or, without one, with augment.raw_to_float)
+        self.device_convert = bool(device_convert) and self.plan is None
         # data.py:517-525 (base_from_tfrecords, normalize=True; data_options.yaml:5 for training): the files are interleaved one
         # slice at a time, each file's slice stream repeated for ever, so that every exam file contributes equally however many
         # slices it holds.  (tf.data's interleave only ever opens `cycle_length` = #cores files when the streams are infinite;
@@ -288,8 +329,11 @@ class TFRecordDataset:
         """uint8 [H, W, Cs] slices, centre-cropped like train_ds's base() call (512 x 512, data.py:97): in file order, or --
         normalize_exams -- one slice from each file in turn, every file restarting when it runs out (endless)."""
         if not self.normalize_exams:
-            for path in self.paths:
-                yield from self._file_slices(path)
+            for exams in read_exams_parallel(self.paths, self.slice_types, self.workers):
+                for exam in exams:
+                    s = self._centre(exam.slices, min(512, exam.slices.shape[1]), min(512, exam.slices.shape[2]))
+                    for k in range(len(s)):
+                        yield s[k]
             return
         streams = [self._file_slices(p) for p in self.paths]
         empty = set()
@@ -326,8 +370,8 @@ class TFRecordDataset:
 
     def _slices(self):
         oh, ow = self.output_size
-        for path in self.paths:
-            for exam in read_exams(path, self.slice_types):
+        for exams in read_exams_parallel(self.paths, self.slice_types, self.workers):
+            for exam in exams:
                 s = self._centre(exam.slices, oh, ow).astype(np.float32) / np.float32(255.0)
                 for k in range(len(s)):
                     yield s[k][..., self.feature_idx], s[k][..., self.label_idx]
@@ -352,10 +396,31 @@ class TFRecordDataset:
             warp = augment.solve_warp(*augment.draw_warp(self.rng, len(raws), self.output_size[0], **self.plan.warp))
         return augment.RawBatch(np.stack(raws), augment.draw_params(self.rng, len(raws), self.plan), self.output_size, self.label_idx, warp)
 
+    def _eval_raw(self):
+        from . import augment
+        oh, ow = self.output_size
+        raws = []
+
+        def batch():
+            return augment.RawBatch(np.stack(raws), None, self.output_size, self.label_idx, None)
+
+        for exams in read_exams_parallel(self.paths, self.slice_types, self.workers):
+            for exam in exams:
+                s = self._centre(exam.slices, oh, ow)
+                for k in range(len(s)):
+                    raws.append(s[k])
+                    if len(raws) == self.batch_size:
+                        yield batch()
+                        raws = []
+        if raws and not self.drop_remainder:
+            yield batch()
+
     def __iter__(self):
         while True:
             if self.plan is not None:
                 yield from self._augmented()
+            elif self.device_convert:
+                yield from self._eval_raw()
             else:
                 xs, ys = [], []
                 for x, y in self._slices():

@@ -256,3 +256,38 @@ def test_engine_eval_over_the_staging_ring_equals_the_per_batch_path(gpu, tmp_pa
         for k in a:
             if k != 'loss':
                 assert a[k] == b[k], (step, k)        # integer counts: the metrics are identical
+
+
+@pytest.mark.gpu
+def test_evaluate_tfrecords_with_device_side_conversion(gpu, tmp_path, monkeypatch):
+    """`annotator evaluate` on exam files: uint8 slices through the staging ring, / 255 + feature-label split on the device --
+    the same rows as float batches converted on the host, staged or not"""
+    from dnncancerannotator_amd import data, engine, tfrecord as T
+    from dnncancerannotator_amd.runs.train import make_dataset
+    rng = np.random.default_rng(4)
+    paths = []
+    for e, n in enumerate((5, 3, 6)):
+        s = rng.integers(0, 256, size=(n, 72, 80, 3), dtype=np.uint8)
+        s[..., 2] = (s[..., 2] > 215) * 255
+        p = str(tmp_path / ('exam%d.tfrecords' % e))
+        T.write_records(p, [T.make_example(s, e, e, '/e/%d' % e, 'cancer', ['TRA', 'ADC', 'label'])])
+        paths.append(p)
+    opts = dict(batch_size=4, output_size=(64, 64), slice_types=['ADC', 'label'])
+    config = {'model': 'UNetAnnotator', 'model_options': UNET,
+              'deploy_options': {'optimizer': 'adam', 'loss': {'class_name': 'WeightedCrossentropy', 'config': {'weight_mul': 3.0}},
+                                 'enable_multigpu': False,
+                                 'metrics': [{'Precision': {'thresholds': 0.5, 'name': 'pixel/precision'}},
+                                             {'AUC': {'curve': 'ROC', 'name': 'pixel/AUROC', 'num_thresholds': 50}}]}}
+    save = str(tmp_path / 'run')
+    engine.TFKerasModel(config).train(data.SyntheticDataset(4, 64, 64, 1, n_batches=2, seed=3), save_path=save, max_steps=6, save_freq=6)
+    ds = make_dataset(paths, opts, training=False)
+    assert ds.device_convert and isinstance(next(iter(ds)), augment.RawBatch)
+    rows = {'device': engine.TFKerasModel(config).eval(ds, save_path=save, tag='device')}
+    host = T.TFRecordDataset(paths, opts['slice_types'], 4, output_size=(64, 64))
+    rows['host'] = engine.TFKerasModel(config).eval(host, save_path=save, tag='host')
+    monkeypatch.setenv('DNNCA_NO_FEEDER', '1')
+    rows['device_sync'] = engine.TFKerasModel(config).eval(ds, save_path=save, tag='device_sync')
+    for k in ('host', 'device_sync'):
+        a, b = rows['device'][6], rows[k][6]
+        assert abs(a['loss'] - b['loss']) <= 1e-6 * abs(b['loss']), k
+        assert a['pixel/precision'] == b['pixel/precision'] and a['pixel/AUROC'] == b['pixel/AUROC'], k

@@ -111,6 +111,14 @@ def test_tfrecord_dataset_element_contract(tmp_path):
     crop = exams[0][:2, 2:18, 4:20, :]
     assert np.array_equal(x, crop[..., [0, 2, 1]].astype(np.float32) / np.float32(255.0))
     assert np.array_equal(y, crop[..., 5].astype(np.float32) / np.float32(255.0)) and set(np.unique(y)) <= {0.0, 1.0}
+    # device_convert: the same batches as uint8 RawBatches without draws; their host conversion is the float path bit for bit
+    from dnncancerannotator_amd import augment
+    rawds = list(T.TFRecordDataset([path], want, batch_size=2, output_size=(16, 16), device_convert=True))
+    assert [len(b.raw) for b in rawds] == [2, 2, 1] and all(b.params is None and b.raw.dtype == np.uint8 for b in rawds)
+    assert rawds[0].raw.shape == (2, 16, 16, 4) and rawds[0].label_index == 3
+    for rb, (fx, fy) in zip(rawds, batches):
+        cx, cy = augment.raw_to_float(rb)
+        assert np.array_equal(cx, fx) and np.array_equal(cy, fy) and cx.flags['C_CONTIGUOUS']
     # corruption is detected
     bad = bytearray(raw)
     bad[3] ^= 0x01

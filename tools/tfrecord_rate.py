@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""tfrecord_rate.py -- host-side rate of the TFRecord exam reader and of the datasets on top of it (slices per second), and,
+with a GPU, of `engine._evaluate` fed by them.  Writes four synthetic exam files (24 slices of 512 x 512 x 3 uint8 each) first.
+
+    python tools/tfrecord_rate.py [--dir /tmp/tfr] [--gpu]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dnncancerannotator_amd import tfrecord as T        # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--dir', default='/tmp/tfr')
+ap.add_argument('--gpu', action='store_true')
+ap.add_argument('--exams', type=int, default=4)
+a = ap.parse_args()
+os.makedirs(a.dir, exist_ok=True)
+rng = np.random.default_rng(0)
+paths = []
+for e in range(a.exams):
+    p = os.path.join(a.dir, 'exam%d.tfrecords' % e)
+    if not os.path.exists(p):
+        sl = rng.integers(0, 256, size=(24, 512, 512, 3), dtype=np.uint8)
+        sl[..., 2] = (sl[..., 2] > 250) * 255
+        T.write_records(p, [T.make_example(sl, 1, e, 'p', 'c', ['TRA', 'ADC', 'label'])])
+    paths.append(p)
+types = ['TRA', 'label']
+
+
+def rate(name, it, count):
+    for _ in range(2):          # the second pass: page cache and allocator warm
+        t0, n = time.perf_counter(), 0
+        for el in it():
+            n += count(el)
+        dt = time.perf_counter() - t0
+    print('%-44s %5d slices %7.3f s %9.1f slices/s' % (name, n, dt, n / dt), flush=True)
+
+
+rate('read_exams (2 of 3 channels)', lambda: (ex for p in paths for ex in T.read_exams(p, types)), lambda ex: len(ex.slices))
+rate('eval dataset, float32 on the host', lambda: T.TFRecordDataset(paths, types, 8), lambda b: len(b[0]))
+rate('eval dataset, uint8 RawBatch (device_convert)', lambda: T.TFRecordDataset(paths, types, 8, device_convert=True), lambda b: len(b.raw))
+rate('train dataset, uint8 RawBatch 256 x 256', lambda: T.TFRecordDataset(paths, types, 8, output_size=(256, 256), augment_options=None,
+                                                                        buffer_size=32), lambda b: len(b.raw))
+if a.gpu:
+    from dnncancerannotator_amd.engine import TFKerasModel
+    config = dict(model='UNetAnnotator',
+                  model_options=dict(n_filters_first=3, n_downsample=3, rate=2, kernel_size=3, conv_stride=1, bn=False, padding='same'),
+                  deploy_options=dict(optimizer='adam', loss=dict(class_name='WeightedCrossentropy', config=dict(weight_mul=3.0)),
+                                      enable_multigpu=False,
+                                      metrics=[{'Precision': {'thresholds': 0.8, 'name': 'pixel/precision'}},
+                                               {'AUC': {'curve': 'ROC', 'name': 'pixel/AUROC', 'num_thresholds': 150}}]))
+    eng = TFKerasModel(config)
+    for name, ds, staged in (('evaluate: float on the host, per batch', T.TFRecordDataset(paths, types, 8), False),
+                             ('evaluate: float on the host, staging ring', T.TFRecordDataset(paths, types, 8), True),
+                             ('evaluate: uint8 to the device, staging ring', T.TFRecordDataset(paths, types, 8, device_convert=True), True)):
+        eng._build(ds)
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = eng._evaluate(ds, staged=staged)
+            dt = time.perf_counter() - t0
+        print('%-44s %5d slices %7.3f s %9.1f slices/s (loss %.6f)' % (name, 24 * a.exams, dt, 24 * a.exams / dt, r['loss']), flush=True)
