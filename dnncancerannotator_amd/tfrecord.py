@@ -284,7 +284,7 @@ class TFRecordDataset:
 
     def __init__(self, paths, slice_types, batch_size, output_size=(512, 512), repeat=False, drop_remainder=False,
                  augment_options=False, buffer_size=0, seed=0, normalize_exams=False, device_convert=False, workers=None,
-                 **ignored):
+                 cache_bytes=8 << 30, **ignored):
         from . import augment
         self.paths = list(paths)
         self.slice_types = list(slice_types)
@@ -298,6 +298,10 @@ class TFRecordDataset:
             self.output_size = self.plan.output_size
         self.buffer_size = int(buffer_size)
         self.workers = workers                # reader threads (None: half the cores, at most eight)
+        # decoded exams (uint8, channels picked) stay in host memory up to `cache_bytes`: the endless training stream re-reads
+        # every file each time its slices run out (data.py:517-525), and `annotator evaluate` walks the files once per checkpoint
+        self.cache_bytes = int(cache_bytes)
+        self._cache, self._cached_bytes = {}, 0
         # evaluation with device_convert: the centre-cropped uint8 slices travel as `augment.RawBatch`es without draws (params None)
         # -- a quarter of the float bytes over PCIe, no float copy of an exam on the host; the engine converts them on the device
         # (or, without one, with augment.raw_to_float)
@@ -313,13 +317,33 @@ class TFRecordDataset:
         self.element_spec = (Spec((self.batch_size,) + self.output_size + (len(self.feature_idx),), np.float32),
                              Spec((self.batch_size,) + self.output_size, np.float32))
 
+    def _exams_of(self, path, exams=None):
+        """the decoded exams of one file, from the cache when they are there (`exams`: just read by the caller -> remember them)"""
+        got = self._cache.get(path)
+        if got is not None:
+            return got
+        if exams is None:
+            exams = list(read_exams(path, self.slice_types))
+        size = sum(e.slices.nbytes for e in exams)
+        if self._cached_bytes + size <= self.cache_bytes:
+            self._cache[path] = exams
+            self._cached_bytes += size
+        return exams
+
+    def _exam_lists(self):
+        """[exams of file 0], [exams of file 1], ... -- cached files at once, the others through the reader threads"""
+        missing = [p for p in self.paths if p not in self._cache]
+        fresh = read_exams_parallel(missing, self.slice_types, self.workers)
+        for p in self.paths:
+            yield self._exams_of(p) if p in self._cache else self._exams_of(p, next(fresh))
+
     @staticmethod
     def _centre(s, oh, ow):
         gy, gx = (s.shape[1] - oh) // 2, (s.shape[2] - ow) // 2
         return s[:, gy:gy + oh, gx:gx + ow, :]
 
     def _file_slices(self, path):
-        for exam in read_exams(path, self.slice_types):
+        for exam in self._exams_of(path):
             s = exam.slices
             s = self._centre(s, min(512, s.shape[1]), min(512, s.shape[2]))
             for k in range(len(s)):
@@ -329,7 +353,7 @@ class TFRecordDataset:
         """uint8 [H, W, Cs] slices, centre-cropped like train_ds's base() call (512 x 512, data.py:97): in file order, or --
         normalize_exams -- one slice from each file in turn, every file restarting when it runs out (endless)."""
         if not self.normalize_exams:
-            for exams in read_exams_parallel(self.paths, self.slice_types, self.workers):
+            for exams in self._exam_lists():
                 for exam in exams:
                     s = self._centre(exam.slices, min(512, exam.slices.shape[1]), min(512, exam.slices.shape[2]))
                     for k in range(len(s)):
@@ -370,7 +394,7 @@ class TFRecordDataset:
 
     def _slices(self):
         oh, ow = self.output_size
-        for exams in read_exams_parallel(self.paths, self.slice_types, self.workers):
+        for exams in self._exam_lists():
             for exam in exams:
                 s = self._centre(exam.slices, oh, ow).astype(np.float32) / np.float32(255.0)
                 for k in range(len(s)):
@@ -404,7 +428,7 @@ class TFRecordDataset:
         def batch():
             return augment.RawBatch(np.stack(raws), None, self.output_size, self.label_idx, None)
 
-        for exams in read_exams_parallel(self.paths, self.slice_types, self.workers):
+        for exams in self._exam_lists():
             for exam in exams:
                 s = self._centre(exam.slices, oh, ow)
                 for k in range(len(s)):

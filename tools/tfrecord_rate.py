@@ -63,3 +63,20 @@ if a.gpu:
             r = eng._evaluate(ds, staged=staged)
             dt = time.perf_counter() - t0
         print('%-44s %5d slices %7.3f s %9.1f slices/s (loss %.6f)' % (name, 24 * a.exams, dt, 24 * a.exams / dt, r['loss']), flush=True)
+
+    # `annotator train` on the exam files: data_options.yaml train (256 x 256 random crops, shuffle buffer), augmentation on the device
+    import os as _os
+    for name, env in (('train: loop uploads every batch itself', '1'), ('train: feeder thread + staging ring', '')):
+        if env:
+            _os.environ['DNNCA_NO_FEEDER'] = env
+        else:
+            _os.environ.pop('DNNCA_NO_FEEDER', None)
+        tr = TFKerasModel(config)
+        ds = T.TFRecordDataset(paths, types, 8, output_size=(256, 256), augment_options=None, buffer_size=64, repeat=True,
+                               drop_remainder=True, normalize_exams=True)
+        tr.train(ds, max_steps=30, auto_resume=False)
+        steps = 400
+        t0 = time.perf_counter()
+        tr.train(ds, max_steps=30 + steps, auto_resume=False)
+        dt = time.perf_counter() - t0
+        print('%-44s %5d slices %7.3f s %9.1f slices/s' % (name, 8 * steps, dt, 8 * steps / dt), flush=True)
