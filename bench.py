@@ -209,6 +209,27 @@ def main():
             'hip_event_ms_per_step': round(ev_ms / args.steps, 4),
             'final_loss': round(float(out.loss), 6),
         }
+        if world == 1 and args.workload == 'unet':
+            # informative, never `value`: the same steps with every batch starting in (pageable) host memory -- uploads into the
+            # model's staging ring on the copy stream, step scalars read one step late (tools/e2e_rate.py)
+            ring = model.staging()
+            hb = [synthetic_batch(BATCH_PER_GPU, H, W, C, seed_x=300 + i, seed_y=400 + i) for i in range(2)]
+            n_host, prev = max(20, args.steps // 2), None
+            model.sync()
+            th = time.perf_counter()
+            for i in range(n_host):
+                slot = i % ring.slots
+                px, py = ring.upload(slot, hb[i % 2][0], hb[i % 2][1], wait=False)
+                ring.train_step(slot, px, py, BATCH_PER_GPU, lr, cfg)
+                if prev is not None:
+                    ring.out(prev)
+                prev = slot
+            ring.out(prev)
+            th = time.perf_counter() - th
+            line['from_host_memory'] = {'value': round(BATCH_PER_GPU * n_host / th, 1), 'unit': 'slices/s', 'steps': n_host,
+                                        'ms_per_step': round(1e3 * th / n_host, 4),
+                                        'note': 'PCIe-inclusive: %.1f MB per step from pageable host arrays through the staging ring'
+                                                % ((hb[0][0].nbytes + hb[0][1].nbytes) / 1e6)}
         if world == 1 and not args.no_cpu_baseline and args.workload == 'unet':
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
