@@ -146,6 +146,13 @@ class TFKerasModel:
         lo, hi = distributed.shard_bounds(len(x), self.ctx.rank, self.ctx.world, even=False)
         return x[lo:hi], (None if y is None else y[lo:hi])
 
+    def _shard_fn(self, dataset):
+        """the split for the elements of `dataset`: none for one rank and for datasets that hand every rank its part already
+        (tfrecord.TFRecordDataset(shard=...): `pre_sharded`)"""
+        if self.ctx.world == 1 or getattr(dataset, 'pre_sharded', False):
+            return lambda x, y=None: (x, y)
+        return self._shard
+
     # ---- checkpoints (engine.py:55-78, 103-106, 224-231) -----------------------------------------------------
     def get_ckpts(self, base_path):
         regex_pattern = fr'^{self.ckpt_pattern}\.index$'.format(epoch=r'(\d+)')
@@ -216,6 +223,7 @@ class TFKerasModel:
         results = History(self.model)
         results.params = dict(epochs=max_steps, steps=1, verbose=0)
         best_val, wait = np.inf, 0
+        shard = self._shard_fn(dataset)
         source = iter(dataset)
         step = self.current_step
         if profile:
@@ -231,7 +239,7 @@ class TFKerasModel:
             except StopIteration:
                 first = None
             if first is not None:
-                feeder = source = BatchFeeder(dm, source, self._shard, first=first)
+                feeder = source = BatchFeeder(dm, source, shard, first=first)
             else:
                 source = iter(())
         pending = None          # (slot, step, lr) of an enqueued step whose scalars have not been read
@@ -275,23 +283,23 @@ class TFKerasModel:
                 elif item[0] == 'raw':               # uint8 source batch in a staging slot: augmentation kernels, then the step
                     _, slot, src, batch, n = item
                     feeder.ring.wait(slot)
-                    params, _ = self._shard(batch.params)
-                    xb, yb = dm.augment_u8(self._shard(batch.raw)[0], params, batch.output_size, batch.label_index, src_ptr=src)
+                    params, _ = shard(batch.params)
+                    xb, yb = dm.augment_u8(shard(batch.raw)[0], params, batch.output_size, batch.label_index, src_ptr=src)
                     if batch.warp is not None:
-                        xb, yb = dm.warp(xb, yb, self._shard(batch.warp[0])[0], self._shard(batch.warp[1])[0])
+                        xb, yb = dm.warp(xb, yb, shard(batch.warp[0])[0], shard(batch.warp[1])[0])
                     feeder.ring.train_step(slot, xb.ptr, yb.ptr, n, self.learning_rate, cfg)
                 else:
                     batch = item[1]
                     if isinstance(batch, augment.RawBatch):
                         # uint8 slices + their random draws: crop / flip / contrast / 255 / feature-label split on the device
-                        raw, _ = self._shard(batch.raw)
-                        params, _ = self._shard(batch.params)
+                        raw, _ = shard(batch.raw)
+                        params, _ = shard(batch.params)
                         xb, yb = dm.augment_u8(raw, params, batch.output_size, batch.label_index)
                         if batch.warp is not None:
-                            xb, yb = dm.warp(xb, yb, self._shard(batch.warp[0])[0], self._shard(batch.warp[1])[0])
+                            xb, yb = dm.warp(xb, yb, shard(batch.warp[0])[0], shard(batch.warp[1])[0])
                         out = dm.train_step_dev(xb, yb, len(raw), self.learning_rate, cfg, want_out=True)
                     else:
-                        x, y = self._shard(np.asarray(batch[0]), np.asarray(batch[1]))
+                        x, y = shard(np.asarray(batch[0]), np.asarray(batch[1]))
                         out = dm.train_step(x, y, self.learning_rate, cfg)
                 step += 1
                 self.current_step = step
@@ -341,11 +349,12 @@ class TFKerasModel:
         for m in self.metrics:
             m.reset_state()
         total, count = 0.0, 0
+        shard = self._shard_fn(dataset)
         if staged and self._staged_eval_possible():
-            total, count, dataset = self._evaluate_staged(dataset, cfg_kw)      # what is left: batches the ring could not take
+            total, count, dataset = self._evaluate_staged(dataset, cfg_kw, shard)      # what is left: batches the ring could not take
         for el in dataset:
             x, y = augment.raw_to_float(el) if isinstance(el, augment.RawBatch) else el
-            x, y = self._shard(np.asarray(x), np.asarray(y))
+            x, y = shard(np.asarray(x), np.asarray(y))
             if len(x):
                 self._ensure_capacity(len(x))
             dm = self.device_model
@@ -388,7 +397,7 @@ class TFKerasModel:
         return (hasattr(self.device_model, 'staging') and not os.environ.get('DNNCA_NO_FEEDER') and n_thr <= 1024 and
                 all(hasattr(m, 'thresholds') and hasattr(m, 'counts') for m in self.metrics))
 
-    def _evaluate_staged(self, dataset, cfg_kw):
+    def _evaluate_staged(self, dataset, cfg_kw, shard):
         """The test steps of _evaluate over the staging ring (feeder.py): batches travel to HBM on the copy stream while the
         previous one is evaluated, every metric's thresholds share ONE confusion histogram that stays on the device and is read
         once at the end (exact integer counts), and a batch's loss is read one step late.  Returns (loss sum, sample count,
@@ -399,9 +408,9 @@ class TFKerasModel:
             first = next(source)
         except StopIteration:
             return 0.0, 0, []
-        self._ensure_capacity(len(self._shard(np.asarray(first.raw if isinstance(first, augment.RawBatch) else first[0]))[0]))
+        self._ensure_capacity(len(shard(np.asarray(first.raw if isinstance(first, augment.RawBatch) else first[0]))[0]))
         dm = self.device_model
-        feeder = BatchFeeder(dm, source, self._shard, first=first)
+        feeder = BatchFeeder(dm, source, shard, first=first)
         ring = feeder.ring
         thr = np.concatenate([m.thresholds for m in self.metrics]) if self.metrics else np.zeros(0, np.float32)
         cfg = dm.loss_cfg(**cfg_kw)
@@ -415,7 +424,7 @@ class TFKerasModel:
                 if item[0] == 'raw':         # uint8 slices in the slot: centre crop, / 255 and the feature-label split on the device
                     _, slot, src, batch, n = item
                     ring.wait(slot)
-                    xv, yv = dm.augment_u8(self._shard(batch.raw)[0], augment.plain_params(n), batch.output_size, batch.label_index,
+                    xv, yv = dm.augment_u8(shard(batch.raw)[0], augment.plain_params(n), batch.output_size, batch.label_index,
                                            contrast_channels=(), src_ptr=src)
                     px, py = xv.ptr, yv.ptr
                 else:

@@ -50,7 +50,7 @@ class BatchFeeder:
     def _stage(self, batch):
         if isinstance(batch, augment.RawBatch):
             raw = np.ascontiguousarray(self.shard(batch.raw)[0], np.uint8)
-            if not self.ring.fits(raw):
+            if not len(raw) or not self.ring.fits(raw):
                 return ('host', batch)
             slot = self.free.get()
             if slot is None:

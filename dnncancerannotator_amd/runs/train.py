@@ -18,7 +18,9 @@ def make_dataset(paths, options, training):
         c = dims[2] if len(dims) > 2 else 1
         return data.SyntheticDataset(batch_size, h, w, c, repeat=training, n_batches=4 if training else 2)
     if all(p.endswith('.tfrecords') for p in paths):          # the reference's exam files (data.py:166-169)
+        from .. import distributed
         from ..tfrecord import TFRecordDataset
+        ctx = distributed.context()
         slice_types = options.get('slice_types', ['TRA', 'ADC', 'DWI', 'DCEE', 'DCEL', 'label'])
         # train_ds (data.py:62-111): output_size defaults to 256 x 256 and there is always at least the random crop;
         # eval_ds (data.py:114-143): centre crop to output_size (default 512 x 512), no augmentation
@@ -28,6 +30,7 @@ def make_dataset(paths, options, training):
                                augment_options=options.get('augment_options') if training else False,
                                buffer_size=options.get('buffer_size', 0) if training else 0,
                                device_convert=not training,      # evaluation: uint8 to the device, / 255 and the split there
+                               shard=(ctx.rank, ctx.world),      # data parallel: every rank assembles only its part of a batch
                                normalize_exams=bool(options.get('normalize_exams', True)) if training else False)   # data.py:68,137
     if all(p.endswith('.npz') for p in paths):
         import numpy as np

@@ -284,7 +284,7 @@ class TFRecordDataset:
 
     def __init__(self, paths, slice_types, batch_size, output_size=(512, 512), repeat=False, drop_remainder=False,
                  augment_options=False, buffer_size=0, seed=0, normalize_exams=False, device_convert=False, workers=None,
-                 cache_bytes=8 << 30, **ignored):
+                 cache_bytes=8 << 30, shard=None, **ignored):
         from . import augment
         self.paths = list(paths)
         self.slice_types = list(slice_types)
@@ -298,6 +298,13 @@ class TFRecordDataset:
             self.output_size = self.plan.output_size
         self.buffer_size = int(buffer_size)
         self.workers = workers                # reader threads (None: half the cores, at most eight)
+        # data parallel, one process per GPU: shard = (rank, world) makes every batch this rank's contiguous part of the global
+        # batch (engine._shard's split, done BEFORE the slices are stacked, solved for and uploaded -- every rank walks the same
+        # slice stream and makes the same draws, but only pays for its own part).  element_spec keeps the global batch size.
+        self.rank, self.world = (int(shard[0]), int(shard[1])) if shard else (0, 1)
+        self.pre_sharded = self.world > 1
+        if self.pre_sharded and augment_options is not False and self.batch_size % self.world:
+            raise ValueError('global batch %d is not divisible by %d ranks' % (self.batch_size, self.world))
         # decoded exams (uint8, channels picked) stay in host memory up to `cache_bytes`: the endless training stream re-reads
         # every file each time its slices run out (data.py:517-525), and `annotator evaluate` walks the files once per checkpoint
         self.cache_bytes = int(cache_bytes)
@@ -336,6 +343,14 @@ class TFRecordDataset:
         fresh = read_exams_parallel(missing, self.slice_types, self.workers)
         for p in self.paths:
             yield self._exams_of(p) if p in self._cache else self._exams_of(p, next(fresh))
+
+    def _mine(self, items):
+        """this rank's contiguous part of a global batch (a remainder goes to the first ranks: no evaluation sample is dropped)"""
+        if self.world == 1:
+            return items
+        from .distributed import shard_bounds
+        lo, hi = shard_bounds(len(items), self.rank, self.world, even=False)
+        return items[lo:hi]
 
     @staticmethod
     def _centre(s, oh, ow):
@@ -417,8 +432,16 @@ class TFRecordDataset:
         if self.plan.warp is not None:
             if self.output_size[0] != self.output_size[1]:
                 raise ValueError('random_warp supports square images only (data.py:746 asserts width == height)')
-            warp = augment.solve_warp(*augment.draw_warp(self.rng, len(raws), self.output_size[0], **self.plan.warp))
-        return augment.RawBatch(np.stack(raws), augment.draw_params(self.rng, len(raws), self.plan), self.output_size, self.label_idx, warp)
+            src, dst = augment.draw_warp(self.rng, len(raws), self.output_size[0], **self.plan.warp)      # draws for the global batch
+            warp = augment.solve_warp(self._mine(src), self._mine(dst))
+        params = self._mine(augment.draw_params(self.rng, len(raws), self.plan))
+        return augment.RawBatch(np.stack(self._mine(raws)), params, self.output_size, self.label_idx, warp)
+
+    def _stacked(self, xs, ys):
+        mx, my = self._mine(xs), self._mine(ys)
+        if not mx:
+            return np.zeros((0,) + xs[0].shape, np.float32), np.zeros((0,) + ys[0].shape, np.float32)
+        return np.stack(mx), np.stack(my)
 
     def _eval_raw(self):
         from . import augment
@@ -426,7 +449,9 @@ class TFRecordDataset:
         raws = []
 
         def batch():
-            return augment.RawBatch(np.stack(raws), None, self.output_size, self.label_idx, None)
+            mine = self._mine(raws)
+            raw = np.stack(mine) if mine else np.zeros((0,) + raws[0].shape, np.uint8)
+            return augment.RawBatch(raw, None, self.output_size, self.label_idx, None)
 
         for exams in self._exam_lists():
             for exam in exams:
@@ -451,9 +476,9 @@ class TFRecordDataset:
                     xs.append(x)
                     ys.append(y)
                     if len(xs) == self.batch_size:
-                        yield np.stack(xs), np.stack(ys)
+                        yield self._stacked(xs, ys)
                         xs, ys = [], []
                 if xs and not self.drop_remainder:
-                    yield np.stack(xs), np.stack(ys)
+                    yield self._stacked(xs, ys)
             if not self.repeat:
                 return

@@ -151,3 +151,36 @@ def test_normalize_exams_interleaves_files_equally(tmp_path):
     assert [int(b.raw[k, 20, 20, 0]) for b in (next(it) for _ in range(2)) for k in range(3)] == [10, 11, 12, 13, 14, 15]
     with pytest.raises(ValueError):
         T.TFRecordDataset(paths, types, 3, output_size=(32, 32), normalize_exams=True)       # needs the endless training stream
+
+
+def test_dataset_level_sharding_for_data_parallel(tmp_path):
+    """shard=(rank, world): every rank walks the same slice stream and makes the same draws but assembles only its contiguous part
+    of each global batch (engine._shard's split, before stacking / solving / uploading); evaluation remainders go to the first ranks"""
+    from dnncancerannotator_amd import tfrecord as T
+    rng = np.random.default_rng(3)
+    paths = []
+    for i, n in enumerate((5, 4)):
+        s = rng.integers(0, 256, size=(n, 40, 40, 2), dtype=np.uint8)
+        p = str(tmp_path / ('exam%d.tfrecords' % i))
+        T.write_records(p, [T.make_example(s, i, i, '/e/%d' % i, 'cancer', ['TRA', 'label'])])
+        paths.append(p)
+    kw = dict(output_size=(32, 32), repeat=True, drop_remainder=True, augment_options={'random_crop': {}, 'random_flip': {}},
+              buffer_size=4, seed=7)
+    whole = T.TFRecordDataset(paths, ['TRA', 'label'], 4, **kw)
+    parts = [T.TFRecordDataset(paths, ['TRA', 'label'], 4, shard=(r, 2), **kw) for r in range(2)]
+    assert not whole.pre_sharded and all(p.pre_sharded and p.element_spec[0].shape[0] == 4 for p in parts)
+    its = [iter(whole)] + [iter(p) for p in parts]
+    for _ in range(5):
+        w, a, b = (next(it) for it in its)
+        assert np.array_equal(np.concatenate([a.raw, b.raw]), w.raw) and list(a.params) + list(b.params) == list(w.params)
+        assert len(a.raw) == len(b.raw) == 2
+    with pytest.raises(ValueError):
+        T.TFRecordDataset(paths, ['TRA', 'label'], 3, shard=(0, 2), **kw)          # a training batch must divide evenly
+    # evaluation: 9 slices in batches of 4 -> 4, 4, 1; the last batch's single slice goes to rank 0, rank 1 gets an empty batch
+    for dc in (False, True):
+        ev = [list(T.TFRecordDataset(paths, ['TRA', 'label'], 4, output_size=(32, 32), shard=(r, 2), device_convert=dc)) for r in range(2)]
+        full = list(T.TFRecordDataset(paths, ['TRA', 'label'], 4, output_size=(32, 32), device_convert=dc))
+        first = (lambda el: el.raw) if dc else (lambda el: el[0])
+        assert [len(first(el)) for el in ev[0]] == [2, 2, 1] and [len(first(el)) for el in ev[1]] == [2, 2, 0]
+        for f, a, b in zip(full, ev[0], ev[1]):
+            assert np.array_equal(np.concatenate([first(a), first(b)]), first(f))
