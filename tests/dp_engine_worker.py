@@ -63,13 +63,30 @@ def main():
     m = engine.TFKerasModel(CONFIG)
     res = m.train(train, val_data=val, save_path=save, max_steps=4, save_freq=2)
     dm = m.device_model
-    result = dict(rank=ctx.rank, built=built, max_batch=dm.max_batch, calls=dm.calls,
+    result = dict(rank=ctx.rank, built=list(built), max_batch=dm.max_batch, calls=dm.calls,
                   params=dm.get_params().astype(np.float64).tolist(), state=dm.get_state().astype(np.float64).tolist(),
                   loss=res.history['loss'], val_loss=res.history.get('val_loss'),
                   val_auprc=res.history.get('val_pixel/AUPRC'), val_precision=res.history.get('val_pixel/precision'),
                   files=sorted(os.listdir(os.path.join(save, 'checkpoints'))) if os.path.isdir(os.path.join(save, 'checkpoints')) else None)
     ev = m._evaluate(val)
     result['eval'] = {k: v for k, v in ev.items()}
+
+    # the same job on datasets that hand every rank its part already (tfrecord.TFRecordDataset(shard=...): pre_sharded, the
+    # element spec still names the global batch): the engine must not split again
+    class PreSharded:
+        pre_sharded = True
+
+        def __init__(self, ds):
+            self.ds, self.element_spec = ds, ds.element_spec
+
+        def __iter__(self):
+            for x, y in self.ds:
+                lo, hi = distributed.shard_bounds(len(x), ctx.rank, ctx.world, even=False)
+                yield x[lo:hi], y[lo:hi]
+
+    m2 = engine.TFKerasModel(CONFIG)
+    res2 = m2.train(PreSharded(train), val_data=PreSharded(val), save_path=save + '_presharded', max_steps=4, save_freq=2)
+    result['loss_presharded'], result['val_loss_presharded'] = res2.history['loss'], res2.history.get('val_loss')
     result['auc_counts'] = m.metrics[1].counts.tolist()
     dist.barrier()
     if ctx.rank == 0:

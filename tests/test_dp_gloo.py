@@ -79,6 +79,9 @@ def test_engine_world2(tmp_path):
     assert r0['auc_counts'] == r0['ref_auc_counts'] == r1['auc_counts']
     assert np.array(r0['auc_counts']).sum(1).tolist() == [11 * 16 * 16] * 150
     assert r0['eval']['loss'] == r1['eval']['loss'] and 0.0 <= r0['eval']['pixel/AUROC'] <= 1.0
+    # datasets that shard themselves (pre_sharded): the same losses, nothing is split twice
+    assert r0['loss_presharded'] == r0['loss'] and r1['loss_presharded'] == r1['loss']
+    assert r0['val_loss_presharded'] == r0['val_loss']
     # rank 0 alone wrote the checkpoints; the rendezvous file is gone
     assert r0['files'] == ['ckpt-2.data-00000-of-00001', 'ckpt-2.index', 'ckpt-4.data-00000-of-00001', 'ckpt-4.index']
     assert not os.path.exists(tmp_path / ('dnnca_rdzv_pytest_%d.id' % port))
