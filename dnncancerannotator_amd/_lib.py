@@ -91,6 +91,7 @@ SIGNATURES = {
     'dnnca_forward_dev': (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     'dnnca_last_step_out': (C.c_int, [_VP, C.POINTER(StepOut)]),
     'dnnca_sync': (C.c_int, [_VP]),
+    'dnnca_crc32c': (C.c_int, [_VP, C.c_size_t, C.POINTER(C.c_uint32)]),
     'dnnca_stage_init': (C.c_int, [_VP, C.c_int, C.c_size_t]),
     'dnnca_stage_upload': (C.c_int, [_VP, C.c_int, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(_VP), C.POINTER(_VP)]),
     'dnnca_stage_uploaded': (C.c_int, [_VP, C.c_int]),

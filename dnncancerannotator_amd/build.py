@@ -12,6 +12,9 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-u
 # per-file extras.  kernels_mfma.hip: no SLP vectorizer -- it packs the scalar FMA chains of k_bwd3v into v_pk_fma_f32 (no faster
 # than two v_fma_f32 on gfx950, and the even-aligned register pairs cost hundreds of v_mov and spills)
 EXTRA_FLAGS = {'kernels_mfma.hip': ['-fno-slp-vectorize']}
+# host-only C++ (no device pass): compiled by the same driver as plain C++
+HOST_SOURCES = ['host_util.cpp']
+HOST_FLAGS = ['-O3', '-std=c++17', '-fPIC', '-Wall']
 
 
 def _newer(src_list, target):
@@ -34,6 +37,15 @@ def build_library(force=False, verbose=False):
         objs.append(o)
         if force or _newer([s] + headers, o):
             cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (['-DDNNCA_TUNING'] if os.environ.get('DNNCA_TUNING') else []) + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src in HOST_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace('.cpp', '.o'))
+        objs.append(o)
+        if force or _newer([s] + headers, o):
+            cmd = [hipcc, '-x', 'c++'] + HOST_FLAGS + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -35,7 +35,34 @@ def _crc_table():
     return _CRC_TABLE
 
 
+_native_crc = None
+
+
+def _native():
+    """dnnca_crc32c of libdnnca (csrc/host_util.cpp: the SSE4.2 crc32 instruction), or False when the library is not built"""
+    global _native_crc
+    if _native_crc is None:
+        try:
+            import ctypes
+            from . import _lib
+            fn = _lib.load().dnnca_crc32c
+
+            def crc(data):
+                out = ctypes.c_uint32()                           # per call: the reader threads check their files concurrently
+                buf = np.frombuffer(data, np.uint8)              # bytes, bytearray or a (read-only) memoryview: no copy
+                if fn(buf.ctypes.data, buf.size, ctypes.byref(out)) != 0:
+                    raise ValueError('dnnca_crc32c failed')
+                return out.value
+            _native_crc = crc
+        except Exception:
+            _native_crc = False
+    return _native_crc
+
+
 def crc32c(data):
+    native = _native()
+    if native and len(data) > 64:
+        return native(data)
     t = _crc_table()
     c = 0xFFFFFFFF
     for b in bytes(data):
@@ -49,11 +76,14 @@ def masked_crc(data):
 
 
 # ------------------------------------------------------------------------------------------------ TFRecord framing
-def read_records(path, verify_payload_crc=False):
+def read_records(path, verify_payload_crc=None):
     """Yields the payload of every record as a memoryview into a read-only mapping of the file (no copy: an exam's pixels go from
-    the page cache straight into whoever picks them apart).  The 12-byte header CRC is always checked; the payload CRC (a
-    pure-Python loop over megabytes of pixels) only on request."""
+    the page cache straight into whoever picks them apart).  The 12-byte header CRC is always checked; the payload CRC -- as
+    tf.data.TFRecordDataset does -- whenever libdnnca's dnnca_crc32c is there to walk the megabytes of pixels (None), or on
+    request (True: with the byte-wise Python loop if need be)."""
     import mmap
+    if verify_payload_crc is None:
+        verify_payload_crc = bool(_native())
     size = os.path.getsize(path)
     if size == 0:
         return

@@ -160,6 +160,11 @@ int dnnca_forward_dev(void* model, const float* x_dev, int batch, int training);
 int dnnca_last_step_out(void* model, dnnca_step_out* out);        /* synchronises, then reads the last step's scalars */
 int dnnca_sync(void* model);
 
+/* ---- host-side helper of the exam-file reader (dnncancerannotator_amd/tfrecord.py; no device involved) ------------------------
+ * CRC-32C (Castagnoli) of `n` bytes: tf.data.TFRecordDataset (annotator/data.py:448-470) checks the masked CRC-32C of every record
+ * length and payload; the SSE4.2 crc32 instruction where the host has it */
+int dnnca_crc32c(const void* data, size_t n, uint32_t* crc_out);
+
 /* ---- input pipeline: what `ds.prefetch(AUTOTUNE)` (annotator/data.py:110,143) + Keras fit's asynchronous input feeding
  * (engine.py:126-135) do for the reference.  A ring of `slots` (<= 4) staging slots in HBM and a copy stream: the next
  * batch travels host -> HBM while the main stream still works on the previous step, and the step outputs come back through a

@@ -19,6 +19,56 @@ def test_crc32c_known_answers():
     assert T.masked_crc(b'abc') == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
 
 
+def test_native_crc32c_equals_the_table_and_payload_corruption_is_caught(tmp_path):
+    """dnnca_crc32c (csrc/host_util.cpp, SSE4.2) against the byte-wise table on RFC 3720 vectors, odd lengths and unaligned starts;
+    with it the reader checks every payload like tf.data.TFRecordDataset does"""
+    import ctypes
+    from dnncancerannotator_amd import _lib
+    fn = _lib.load().dnnca_crc32c
+
+    def native(b):
+        out = ctypes.c_uint32()
+        buf = np.frombuffer(b, np.uint8)
+        assert fn(buf.ctypes.data if buf.size else None, buf.size, ctypes.byref(out)) == 0
+        return out.value
+
+    def table(b):
+        t, c = T._crc_table(), 0xFFFFFFFF
+        for x in bytes(b):
+            c = int(t[(c ^ x) & 0xFF]) ^ (c >> 8)
+        return c ^ 0xFFFFFFFF
+
+    assert native(b'123456789') == 0xE3069283 and native(b'') == 0
+    assert native(bytes(32)) == 0x8A9136AA and native(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert native(bytes(range(32))) == 0x46DD794E                        # RFC 3720 B.4: incrementing bytes
+    rng = np.random.default_rng(0)
+    blob = rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()
+    for lo, n in ((0, 5000), (1, 4099), (3, 1), (5, 7), (7, 64), (2, 1023)):
+        assert native(blob[lo:lo + n]) == table(blob[lo:lo + n]), (lo, n)
+        assert native(memoryview(blob)[lo:lo + n]) == table(blob[lo:lo + n])
+    assert T.crc32c(blob) == table(blob)                                 # the reader's entry point takes the native path
+    # a flipped payload byte is caught by default now
+    s = rng.integers(0, 256, size=(2, 24, 24, 2), dtype=np.uint8)
+    path = str(tmp_path / 'e.tfrecords')
+    T.write_records(path, [T.make_example(s, 1, 2, '/p', 'c', ['TRA', 'label'])])
+    assert len(list(T.read_records(path))) == 1
+    raw = bytearray(open(path, 'rb').read())
+    raw[len(raw) // 2] ^= 0x40
+    bad = str(tmp_path / 'bad.tfrecords')
+    open(bad, 'wb').write(bytes(raw))
+    with pytest.raises(IOError, match='payload CRC'):
+        list(T.read_records(bad))
+    assert len(list(T.read_records(bad, verify_payload_crc=False))) == 1  # explicit opt-out
+    # the reader threads check their files concurrently
+    paths = []
+    for i in range(6):
+        p = str(tmp_path / ('t%d.tfrecords' % i))
+        T.write_records(p, [T.make_example(rng.integers(0, 256, size=(3, 64, 64, 2), dtype=np.uint8), i, i, '/p', 'c', ['TRA', 'label'])])
+        paths.append(p)
+    for _ in range(5):
+        assert [len(e) for e in T.read_exams_parallel(paths, ['TRA', 'label'], workers=4)] == [1] * 6
+
+
 def _pb_messages():
     """tf.train.Example & friends + the TensorProto subset, declared with google.protobuf (independent of tfrecord.py)."""
     from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
