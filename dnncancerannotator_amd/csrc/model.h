@@ -141,7 +141,7 @@ struct Model {
     // while the main stream is still working on the previous step; the main stream waits for the slot's `uploaded` event, runs
     // the step, sends the step outputs to a pinned host ring and records `done` (the next upload into the slot waits for it,
     // and the host reads the outputs behind it -- normally one step late, so that it never stalls the launch queue).
-    static constexpr int kStageSlots = 4;
+    static constexpr int kStageSlots = 8;     // e.g. four for the train feeder + four for the validation inside train()
     struct StageSlot {
         float *x = nullptr, *y = nullptr;
         hipEvent_t uploaded = nullptr, done = nullptr;

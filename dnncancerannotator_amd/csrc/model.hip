@@ -1050,8 +1050,8 @@ int dnnca_stage_init(void* model, int slots, size_t bytes_per_slot) {
     return DNNCA_OK;
 }
 
-// May be called from a second host thread (one uploader at a time) while the owning thread enqueues steps: it touches only the
-// slot it was handed, the copy stream and the HIP runtime.  With pageable host memory the call returns when the copy is done;
+// May be called from other host threads (each working on slots of its own) while the owning thread enqueues steps: it touches
+// only the slot it was handed, the copy stream and the HIP runtime.  With pageable host memory the call returns when the copy is done;
 // the GPU keeps working on the main stream meanwhile.
 int dnnca_stage_upload(void* model, int slot, const void* host_a, size_t bytes_a, const void* host_b, size_t bytes_b,
                        void** a_dev, void** b_dev) {

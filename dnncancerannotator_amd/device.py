@@ -98,9 +98,9 @@ class StagingRing:
     """The model's staging slots in HBM + its copy stream (include/dnnca.h, dnnca_stage_*): what ds.prefetch + Keras' asynchronous
     input feeding are for the reference (annotator/data.py:110,143; engine.py:126-135).  `upload` may run on a second thread."""
 
-    MAX_SLOTS = 4
+    MAX_SLOTS = 8          # engine: slots 0-3 feed the train steps, 4-7 the evaluation / validation steps
 
-    def __init__(self, dm, slots=4, slot_bytes=0):
+    def __init__(self, dm, slots=8, slot_bytes=0):
         self.dm, self.slots = dm, int(slots)
         check(dm.lib.dnnca_stage_init(dm.handle, self.slots, int(slot_bytes)))
         x_bytes = dm.max_batch * int(np.prod(dm.in_shape)) * 4

@@ -316,7 +316,7 @@ class TFKerasModel:
                     self.save(os.path.join(save_path, 'checkpoints', self.ckpt_pattern.format(epoch=step)))
                 stop = False
                 if val_data is not None and step % save_freq == 0:
-                    val = self._evaluate(val_data)
+                    val = self._evaluate(val_data, staged=feeder is not None)      # on the ring's evaluation slots
                     extra.update({'val_' + k: v for k, v in val.items()})
                     if early_stop_steps is not None:
                         if val['loss'] < best_val:
@@ -410,7 +410,7 @@ class TFKerasModel:
             return 0.0, 0, []
         self._ensure_capacity(len(shard(np.asarray(first.raw if isinstance(first, augment.RawBatch) else first[0]))[0]))
         dm = self.device_model
-        feeder = BatchFeeder(dm, source, shard, first=first)
+        feeder = BatchFeeder(dm, source, shard, slots=BatchFeeder.EVAL_SLOTS, first=first)
         ring = feeder.ring
         thr = np.concatenate([m.thresholds for m in self.metrics]) if self.metrics else np.zeros(0, np.float32)
         cfg = dm.loss_cfg(**cfg_kw)

@@ -22,18 +22,21 @@ from . import augment
 
 
 class BatchFeeder:
-    def __init__(self, device_model, iterator, shard, slots=4, first=None):
+    TRAIN_SLOTS, EVAL_SLOTS = (0, 1, 2, 3), (4, 5, 6, 7)      # two feeders may work on one ring at a time: validation inside train()
+
+    def __init__(self, device_model, iterator, shard, slots=TRAIN_SLOTS, first=None):
         """iterator: the dataset's iterator; shard(x, y=None) -> this rank's part; first: an element already drawn from it (the
-        caller looked at it to size things) -- it is fed before the iterator's own elements."""
+        caller looked at it to size things) -- it is fed before the iterator's own elements; slots: the ring slots this feeder owns."""
         self.dm, self.it, self.shard = device_model, iterator, shard
         slot_bytes = 0
         if first is not None and isinstance(first, augment.RawBatch):
             slot_bytes = int(np.asarray(shard(first.raw)[0]).nbytes) * 5 // 4      # some room: exams differ in size
-        self.ring = device_model.staging(slots, slot_bytes)
+        self.ring = device_model.staging(slot_bytes=slot_bytes)
+        slots = [s for s in slots if s < self.ring.slots]
         self.free = queue.Queue()
-        for s in range(self.ring.slots):
+        for s in slots:
             self.free.put(s)
-        self.ready = queue.Queue(maxsize=self.ring.slots)
+        self.ready = queue.Queue(maxsize=len(slots))
         self._first = first
         self._stop = False
         self.thread = threading.Thread(target=self._run, name='dnnca-batch-feeder', daemon=True)

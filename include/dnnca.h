@@ -166,13 +166,13 @@ int dnnca_sync(void* model);
 int dnnca_crc32c(const void* data, size_t n, uint32_t* crc_out);
 
 /* ---- input pipeline: what `ds.prefetch(AUTOTUNE)` (annotator/data.py:110,143) + Keras fit's asynchronous input feeding
- * (engine.py:126-135) do for the reference.  A ring of `slots` (<= 4) staging slots in HBM and a copy stream: the next
+ * (engine.py:126-135) do for the reference.  A ring of `slots` (<= 8) staging slots in HBM and a copy stream: the next
  * batch travels host -> HBM while the main stream still works on the previous step, and the step outputs come back through a
  * pinned host ring, so the host never has to wait for the step it has just enqueued.
  *   dnnca_stage_init           once per model; bytes_per_slot 0 = one float batch (x, y) at max_batch
  *   dnnca_stage_upload         copies host_a (and host_b right behind it, 256-byte aligned) into the slot on the copy stream, first
  *                              waiting for the step that consumed the slot's previous content; returns the device addresses.
- *                              May run on a second host thread (one uploader at a time) beside the thread that enqueues steps.
+ *                              May run on other host threads beside the thread that enqueues steps (each on slots of its own).
  *   dnnca_stage_uploaded       blocks the calling host thread until the slot's upload has completed: the host buffers may then be
  *                              reused or freed (hipMemcpyAsync from pageable memory gives no such promise on return)
  *   dnnca_stage_wait           the model's stream waits for the slot's upload (for work other than the step, e.g. dnnca_augment_u8)

@@ -35,7 +35,7 @@ class FakeModel:
     def __init__(self, slot_bytes=1 << 20):
         self.ring = FakeRing(slot_bytes)
 
-    def staging(self, slots, slot_bytes):
+    def staging(self, slots=None, slot_bytes=0):
         return self.ring
 
 
