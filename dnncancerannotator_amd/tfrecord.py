@@ -339,6 +339,7 @@ class TFRecordDataset:
         # every file each time its slices run out (data.py:517-525), and `annotator evaluate` walks the files once per checkpoint
         self.cache_bytes = int(cache_bytes)
         self._cache, self._cached_bytes = {}, 0
+        self._pool, self._ahead, self._index = None, {}, {p: i for i, p in enumerate(self.paths)}
         # evaluation with device_convert: the centre-cropped uint8 slices travel as `augment.RawBatch`es without draws (params None)
         # -- a quarter of the float bytes over PCIe, no float copy of an exam on the host; the engine converts them on the device
         # (or, without one, with augment.raw_to_float)
@@ -355,12 +356,30 @@ class TFRecordDataset:
                              Spec((self.batch_size,) + self.output_size, np.float32))
 
     def _exams_of(self, path, exams=None):
-        """the decoded exams of one file, from the cache when they are there (`exams`: just read by the caller -> remember them)"""
+        """the decoded exams of one file, from the cache when they are there (`exams`: just read by the caller -> remember them).
+        A miss reads the file on a reader thread and, while at it, starts the following uncached files of `paths` as well (the
+        round robin of normalize_exams asks for them in that order): the first pass over a data set runs on `workers` threads."""
         got = self._cache.get(path)
         if got is not None:
             return got
         if exams is None:
-            exams = list(read_exams(path, self.slice_types))
+            workers = self.workers if self.workers is not None else min(8, max(1, (os.cpu_count() or 2) // 2))
+            if workers <= 1:
+                exams = list(read_exams(path, self.slice_types))
+            else:
+                if self._pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool = ThreadPoolExecutor(workers, thread_name_prefix='dnnca-exam-reader')
+                read = lambda q: list(read_exams(q, self.slice_types))      # noqa: E731
+                if path not in self._ahead:
+                    self._ahead[path] = self._pool.submit(read, path)
+                i = self._index.get(path, 0)
+                for q in self.paths[i + 1:i + 1 + workers]:                 # read-ahead window behind the file asked for
+                    if len(self._ahead) > workers:
+                        break
+                    if q not in self._cache and q not in self._ahead:
+                        self._ahead[q] = self._pool.submit(read, q)
+                exams = self._ahead.pop(path).result()
         size = sum(e.slices.nbytes for e in exams)
         if self._cached_bytes + size <= self.cache_bytes:
             self._cache[path] = exams
