@@ -484,7 +484,12 @@ class TFRecordDataset:
             src, dst = augment.draw_warp(self.rng, len(raws), self.output_size[0], **self.plan.warp)      # draws for the global batch
             warp = augment.solve_warp(self._mine(src), self._mine(dst))
         params = self._mine(augment.draw_params(self.rng, len(raws), self.plan))
-        return augment.RawBatch(np.stack(self._mine(raws)), params, self.output_size, self.label_idx, warp)
+        # only the window the random crop can reach travels on (centre +- the jitter bound: the same centre, so the same pixels
+        # come out of dnnca_augment_u8): 268 x 268 of 512 x 512 for the default crop -- a quarter of the bytes to stack and upload
+        m = max(abs(int(self.plan.crop['min_'])), abs(int(self.plan.crop['max_']))) if self.plan.crop is not None else 0
+        oh, ow = self.output_size
+        mine = [self._centre(r[None], min(r.shape[0], oh + 2 * m), min(r.shape[1], ow + 2 * m))[0] for r in self._mine(raws)]
+        return augment.RawBatch(np.stack(mine), params, self.output_size, self.label_idx, warp)
 
     def _stacked(self, xs, ys):
         mx, my = self._mine(xs), self._mine(ys)

@@ -234,3 +234,34 @@ def test_dataset_level_sharding_for_data_parallel(tmp_path):
         assert [len(first(el)) for el in ev[0]] == [2, 2, 1] and [len(first(el)) for el in ev[1]] == [2, 2, 0]
         for f, a, b in zip(full, ev[0], ev[1]):
             assert np.array_equal(np.concatenate([first(a), first(b)]), first(f))
+
+
+def test_training_batches_carry_only_the_window_the_crop_can_reach(tmp_path):
+    """train_ds (data.py:62-111): the random crop moves the 16 x 16 output window by at most +-6 around the centre, so only the
+    centre 28 x 28 of every 40 x 40 slice is stacked and uploaded -- and the augmentation of that window with the batch's own draws
+    equals the augmentation of the whole slice (oracle/augment_oracle.py, the checker of dnnca_augment_u8)"""
+    from dnncancerannotator_amd import tfrecord as T
+    from oracle import augment_oracle as A
+    rng = np.random.default_rng(9)
+    s = rng.integers(0, 256, size=(6, 40, 40, 2), dtype=np.uint8)
+    s[:, 0, 0, 0] = np.arange(6)                      # (outside every window: identifies nothing)
+    s[:, 20, 20, 0] = 100 + np.arange(6)              # the slice's number sits in its centre pixel
+    path = str(tmp_path / 'e.tfrecords')
+    T.write_records(path, [T.make_example(s, 1, 1, '/p', 'c', ['TRA', 'label'])])
+    ds = T.TFRecordDataset([path], ['TRA', 'label'], 3, output_size=(16, 16), repeat=True, drop_remainder=True,
+                           augment_options={'random_crop': {}, 'random_flip': {}, 'random_contrast': {}}, seed=4)
+    it = iter(ds)
+    seen_jitter = set()
+    for _ in range(6):
+        b = next(it)
+        assert b.raw.shape == (3, 28, 28, 2)
+        for k in range(3):
+            which = int(b.raw[k, 14, 14, 0]) - 100
+            assert np.array_equal(b.raw[k], s[which, 6:34, 6:34, :])
+            dy, dx, flip, contrast = b.params[k]
+            seen_jitter.add((dy, dx))
+            xw, yw = A.augment_image(b.raw[k], dy, dx, flip, contrast, (16, 16), 1)
+            xf, yf = A.augment_image(s[which], dy, dx, flip, contrast, (16, 16), 1)
+            # (the contrast mean is taken over the cropped output, so the window changes nothing)
+            assert np.array_equal(xw, xf) and np.array_equal(yw, yf)
+    assert len(seen_jitter) > 3 and max(max(abs(a), abs(b_)) for a, b_ in seen_jitter) <= 6
