@@ -566,7 +566,10 @@ def test_rccl_one_rank_rehearsal(gpu):
     tol = dict(params=1e-3, state=1e-5, grads=1e-4)
     for key, d in out['diff'].items():
         assert d <= max(tol[key], 4 * out['noise'][key]), out
-    np.testing.assert_allclose(out['losses_plain'], out['losses_rccl'], rtol=1e-6)
+    # three steps from host buffers, then three through the staging ring (copy stream, scalars one step late) with the communicator
+    assert len(out['losses_rccl']) == 6
+    np.testing.assert_allclose(out['losses_plain'][:3], out['losses_rccl'][:3], rtol=1e-6)
+    np.testing.assert_allclose(out['losses_plain'][3:], out['losses_rccl'][3:], rtol=1e-4)
     assert out['red'] == [1.5, -2.0]
     assert out['red_big'] is True          # 5000 doubles > 2^40 through the chunked host all-reduce, exact
 

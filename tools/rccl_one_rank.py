@@ -26,6 +26,16 @@ def run(force):
     m.comm_broadcast_weights(0)
     x, y = synthetic_batch(4, 64, 64, 1)
     losses = [float(m.train_step(x, y, 1e-3, m.loss_cfg(weight_mul=3.0)).loss) for _ in range(3)]
+    # the same steps fed through the staging ring (copy stream + scalars one step late) with the communicator in the step
+    ring, ring_losses, prev = m.staging(slots=2), [], None
+    for i in range(3):
+        px, py = ring.upload(i % 2, x, y)
+        ring.train_step(i % 2, px, py, 4, 1e-3, m.loss_cfg(weight_mul=3.0))
+        if prev is not None:
+            ring_losses.append(float(ring.out(prev).loss))
+        prev = i % 2
+    ring_losses.append(float(ring.out(prev).loss))
+    losses += ring_losses
     m.comm_average_state()
     red = m.comm_allreduce([1.5, -2.0], op='max').tolist()
     # metric counts of a 150-threshold AUC (600 counters, more than one staging chunk would be 2050) and counts beyond 2^24
