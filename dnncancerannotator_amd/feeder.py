@@ -33,6 +33,9 @@ class BatchFeeder:
             slot_bytes = int(np.asarray(shard(first.raw)[0]).nbytes) * 5 // 4      # some room: exams differ in size
         self.ring = device_model.staging(slot_bytes=slot_bytes)
         slots = [s for s in slots if s < self.ring.slots]
+        # the loop holds one slot (the step whose scalars it has not read) while it asks for the next element: with fewer than two
+        # slots of its own the feeder only prefetches the elements and the loop uploads them itself
+        self._stage_ok = len(slots) >= 2
         self.free = queue.Queue()
         for s in slots:
             self.free.put(s)
@@ -51,6 +54,8 @@ class BatchFeeder:
             yield el
 
     def _stage(self, batch):
+        if not self._stage_ok:
+            return ('host', batch)
         if isinstance(batch, augment.RawBatch):
             raw = np.ascontiguousarray(self.shard(batch.raw)[0], np.uint8)
             if not len(raw) or not self.ring.fits(raw):

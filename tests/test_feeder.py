@@ -87,6 +87,14 @@ def test_feeder_shards_falls_back_and_reports_errors():
     f.close()
 
 
+def test_feeder_without_enough_slots_only_prefetches():
+    dm, data = FakeModel(), _batches(4)
+    f = BatchFeeder(dm, iter(data), lambda a, b=None: (a, b), slots=(0,))        # one slot: the loop would wait for itself
+    got = list(f)
+    assert [g[0] for g in got] == ['host'] * 4 and all(g[1] is d for g, d in zip(got, data)) and not dm.ring.content
+    f.close()
+
+
 def test_feeder_raw_batches_and_close_while_blocked():
     dm = FakeModel()
     raw = np.arange(2 * 12 * 12 * 2, dtype=np.uint8).reshape(2, 12, 12, 2)
