@@ -1215,6 +1215,7 @@ static int confusion_finish(Model* M, int n, const std::vector<int>& order, dnnc
 }
 
 static int confusion_counts(Model* M, size_t npix, const float* thresholds, int n, dnnca_confusion* out) {
+    if (M->eval_active) { set_error("dnnca_pixel_confusion* inside dnnca_eval_begin .. dnnca_eval_end (the histogram is in use)"); return DNNCA_ESTATE; }
     std::vector<int> order;
     DN_TRY(confusion_begin(M, thresholds, n, order));
     g_confusion_hist(M->stream, npix, M->prob, M->y_stage, M->thr_dev, n, reinterpret_cast<unsigned long long*>(M->conf_dev));

@@ -167,6 +167,18 @@ def test_staging_ring_errors_and_late_assertion(gpu):
     ring.train_step(1, px, py, 2, 1e-3, cfg)
     out = ring.out(1)
     assert out.positive_rate == 0.0 and out.weight == 3.0
+    # staged evaluation: call order is checked, the histogram cannot be borrowed in between
+    with pytest.raises(Exception):
+        ring.eval_step(1, px, py, 2, cfg)                        # no eval_begin
+    ring.eval_begin([0.5, 0.25])
+    with pytest.raises(Exception):
+        m.pixel_confusion(np.zeros((2, 32, 32), np.float32), [0.5])
+    ring.eval_step(1, px, py, 2, cfg)
+    counts = ring.eval_end()
+    assert len(counts) == 2 and sum(counts[0]) == 2 * 32 * 32 and counts[0][0] == 0 and counts[1][1] >= counts[0][1]
+    assert ring.out(1).loss > 0
+    with pytest.raises(Exception):
+        ring.eval_end()                                          # ended already
 
 
 @pytest.mark.gpu
