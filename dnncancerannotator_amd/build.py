@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdnnca.so')
-SOURCES = ['model.hip', 'kernels_generic.hip', 'kernels_mfma.hip', 'kernels_fused.hip', 'kernels_misc.hip', 'kernels_igemm.hip', 'kernels_first.hip', 'kernels_aug.hip', 'debug_tools.hip']
+SOURCES = ['model.hip', 'kernels_generic.hip', 'kernels_mfma.hip', 'kernels_fused.hip', 'kernels_fused_bwd.hip', 'kernels_misc.hip', 'kernels_igemm.hip', 'kernels_first.hip', 'kernels_aug.hip', 'debug_tools.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-unused-result']
 # per-file extras.  kernels_mfma.hip: no SLP vectorizer -- it packs the scalar FMA chains of k_bwd3v into v_pk_fma_f32 (no faster
 # than two v_fma_f32 on gfx950, and the even-aligned register pairs cost hundreds of v_mov and spills)
@@ -27,22 +27,27 @@ def _newer(src_list, target):
 def build_library(force=False, verbose=False):
     """Compile every .hip source to an object and link libdnnca.so.  Returns the library path."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    # DNNCA_TUNING=1: the tuning build (in-kernel stamps, phase switches) lives beside the shipped one -- objects *_t.o,
+    # libdnnca_tuning.so; select it at run time with DNNCA_LIB=<path>
+    tuning = bool(os.environ.get('DNNCA_TUNING'))
+    osuf = '_t.o' if tuning else '.o'
+    lib_path = os.path.join(HERE, 'libdnnca_tuning.so') if tuning else LIB
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(HERE, '..', 'include', 'dnnca.h'))
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        o = os.path.join(CSRC, src.replace('.hip', osuf))
         objs.append(o)
         if force or _newer([s] + headers, o):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (['-DDNNCA_TUNING'] if os.environ.get('DNNCA_TUNING') else []) + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (['-DDNNCA_TUNING'] if tuning else []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src in HOST_SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace('.cpp', '.o'))
+        o = os.path.join(CSRC, src.replace('.cpp', osuf))
         objs.append(o)
         if force or _newer([s] + headers, o):
             cmd = [hipcc, '-x', 'c++'] + HOST_FLAGS + ['-c', s, '-o', o]
@@ -59,12 +64,12 @@ def build_library(force=False, verbose=False):
             print(out.decode(errors='replace'))
     if failed:
         raise RuntimeError('libdnnca build failed')
-    if force or procs or _newer(objs, LIB):
-        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs + ['-L/opt/rocm/lib', '-lrccl']
+    if force or procs or _newer(objs, lib_path):
+        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', lib_path] + objs + ['-L/opt/rocm/lib', '-lrccl']
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == '__main__':

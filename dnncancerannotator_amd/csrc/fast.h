@@ -25,6 +25,15 @@ bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsig
 bool fast_up3_fwd(Model* m, int B, size_t oi);     // last decoder block: transposed conv + two-source conv forward in one column-strip launch
 bool fast_head_in_conv_possible(Model* m);      // would fast_conv_fwd_head take the conv that feeds the head?
 bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid, int* consumed = nullptr);
+// kernels_fused_bwd.hip: the whole BACKWARD of a Downsample / Upsample block of configs/unet.yaml (6- and 12-channel levels) in one
+// launch; `oi` is the block's LAST op (the max-pool / the second conv): ops[oi - 2 .. oi] are consumed when these return true
+bool fused_down_bwd(Model* m, int B, size_t oi);
+bool fused_up_bwd(Model* m, int B, size_t oi);
+// kernels_mfma.hip: what the block-fused kernels need from the pixel-group plan
+constexpr int kPgBuckets = 32;                                 // partial-sum slabs per weight gradient
+bool fast_pg_conv_supported(const Model* m, const Op& o);      // a 3x3 conv of the pixel-group plan
+const float* fast_conv_bmat_dgrad(Model* m, const Op& o);      // prepared data-gradient B operands (all passes), or nullptr
+float* fast_wgrad_slabs(Model* m, const Op& o, int source);    // weight-gradient slabs of (op, source) -- transposed convs: source 0 -- or nullptr
 bool fast_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
 // kernels_first.hip: the one-channel-input 3x3 convs (first layer of every encoder)
 bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);   // bn_next as for ig_conv_fwd

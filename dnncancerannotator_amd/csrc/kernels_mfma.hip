@@ -31,7 +31,7 @@ namespace dnnca {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int TH = 8;          // rows of a block tile
-static constexpr int NBUCKET = 32;    // partial-sum slabs per weight gradient (blocks add into slab blockIdx % NBUCKET)
+static constexpr int NBUCKET = kPgBuckets;    // partial-sum slabs per weight gradient (blocks add into slab blockIdx % NBUCKET)
 
 // geometry of one staged tensor: C channels, tile of TW pixels (+1 halo pixel on each side), rows padded to 16 B
 template <int C, int TW>
@@ -1822,6 +1822,19 @@ const float* fast_conv_bmat(Model* m, const Op& o) {
     PgPlan& pl = g_plans[m];
     auto it = pl.slot.find({&o, 0});
     return it == pl.slot.end() ? nullptr : pl.bmat + it->second;
+}
+
+bool fast_pg_conv_supported(const Model* m, const Op& o) { return conv_supported(m, o); }
+const float* fast_conv_bmat_dgrad(Model* m, const Op& o) {
+    if (!conv_supported(m, o)) return nullptr;
+    PgPlan& pl = g_plans[m];
+    auto it = pl.slot.find({&o, 1});
+    return it == pl.slot.end() ? nullptr : pl.bmat + it->second;
+}
+float* fast_wgrad_slabs(Model* m, const Op& o, int source) {
+    PgPlan& pl = g_plans[m];
+    auto it = pl.wslot.find({&o, source});
+    return it == pl.wslot.end() ? nullptr : pl.slabs + pl.folds[it->second].slab_off;
 }
 
 // Called by model.hip at the top of every forward: (re)derive the B operands from the current weights.

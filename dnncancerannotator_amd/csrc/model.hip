@@ -92,9 +92,15 @@ int Model::wg_side_join() {
 
 int Model::alloc(void** ptr, size_t bytes) {
     if (bytes == 0) bytes = 4;
-    HIP_TRY(hipMalloc(ptr, bytes));
-    allocs.push_back(*ptr);
-    HIP_TRY(hipMemsetAsync(*ptr, 0, bytes, stream));
+    // experiment: skew consecutive allocations by a multiple of DNNCA_ALLOC_SKEW bytes so that equally sized tensors do not alias
+    // in the low address bits
+    static const size_t skew_unit = getenv("DNNCA_ALLOC_SKEW") ? (size_t)atol(getenv("DNNCA_ALLOC_SKEW")) : 0;
+    const size_t skew = skew_unit * (allocs.size() % 31);
+    void* base = nullptr;
+    HIP_TRY(hipMalloc(&base, bytes + skew));
+    allocs.push_back(base);
+    HIP_TRY(hipMemsetAsync(base, 0, bytes + skew, stream));
+    *ptr = static_cast<char*>(base) + skew;
     return DNNCA_OK;
 }
 
@@ -668,6 +674,10 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                         tail_done = nullptr;
                         break;
                     }
+                    if (!generic && i >= 2 && fused_up_bwd(this, B, (size_t)i)) {       // second conv, first conv, transposed conv of a decoder block in one launch
+                        i -= 2;
+                        break;
+                    }
                     if (!generic && (fast_conv_bwd(this, B, o, ob, ib, flops) || fast_first_conv_bwd(this, B, o, ob, ib, flops) ||
                                      ig_conv_bwd(this, B, o, ob, ib, flops))) break;
                     if (!all_f32(o)) return DNNCA_ESTATE;
@@ -697,6 +707,10 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 }
                 case OP_POOL: {
                     double bytes = 4.0 * (2 * nelem(B, o.inA.d) + 2 * nelem(B, o.out.d));
+                    if (!generic && i >= 2 && fused_down_bwd(this, B, (size_t)i)) {     // pool, second conv, first conv of an encoder block in one launch
+                        i -= 2;
+                        break;
+                    }
                     if (!generic && i > 0 && fast_pool_fold(this, o, ops[i - 1])) break;      // rides in the next launch (the conv's backward)
                     if (!generic && fast_pool_bwd(this, B, o, bytes)) break;
                     if (!all_f32(o)) return DNNCA_ESTATE;
