@@ -30,7 +30,7 @@ bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid, int* consumed = nu
 bool fused_down_bwd(Model* m, int B, size_t oi);
 bool fused_up_bwd(Model* m, int B, size_t oi);
 // kernels_mfma.hip: what the block-fused kernels need from the pixel-group plan
-constexpr int kPgBuckets = 32;                                 // partial-sum slabs per weight gradient
+constexpr int kPgBuckets = 16;                                 // partial-sum slabs per weight gradient
 bool fast_pg_conv_supported(const Model* m, const Op& o);      // a 3x3 conv of the pixel-group plan
 const float* fast_conv_bmat_dgrad(Model* m, const Op& o);      // prepared data-gradient B operands (all passes), or nullptr
 float* fast_wgrad_slabs(Model* m, const Op& o, int source);    // weight-gradient slabs of (op, source) -- transposed convs: source 0 -- or nullptr

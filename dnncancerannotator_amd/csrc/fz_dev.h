@@ -126,19 +126,24 @@ struct Conv3 {
         f32x4 acc[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the A operands of K-step i + 1 are read while the MFMAs of step i run (two register sets, the order pinned by scheduling
+        // barriers): left to itself hipcc reads each operand right in front of its MFMA and waits for it -- an exposed LDS round
+        // trip per chain and step (tools/micro/mfma_f32_lds.hip: this form issues at 95 % of the matrix pipe's peak from one wave)
+        float av[2][CH];
+        auto fetch = [&](int i, float (&a)[CH]) {
+            const int s = i / (3 * SR), dy = (i / SR) % 3, k = i % SR;
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s)
+            for (int c = 0; c < CH; ++c) a[c] = c < CH - 1 ? a0[s * ISTRIDE + c * CSTEP + dy * ILS + 4 * k] : al[s * ISTRIDE + dy * ILS + 4 * k];
+        };
+        fetch(0, av[0]);
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+        for (int i = 0; i < KS; ++i) {
+            if (i + 1 < KS) fetch(i + 1, av[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < SR; ++k) {
-                    const float b = breg[(s * 3 + dy) * SR + k];
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const float a = c < CH - 1 ? a0[s * ISTRIDE + c * CSTEP + dy * ILS + 4 * k] : al[s * ISTRIDE + dy * ILS + 4 * k];
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
-                    }
-                }
+            for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][c], breg[i], acc[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (n < 12) {
             float* o0 = out + OLEAD + (wave * 16 + 4 * q) * 12 + n;
 #pragma unroll

@@ -296,23 +296,29 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
             // dz1 = (skip gradient + (window position == recorded position ? pooled gradient : 0)) * act'(y1)
             const unsigned char* ixb = reinterpret_cast<const unsigned char*>(lds + O_PIX);
             const float* pdp = lds + O_PDP;
+            static_assert(SDZ::LEAD == 0 && F % 2 == 0 && PFLS % 2 == 0 && (PFLEAD % 2) == 0, "PF transform works on aligned channel pairs");
 #pragma unroll
             for (int k = 0; k < SDZ::NPF; ++k) {
                 const int idx = tid + k * NT;
                 const int r = idx / SDZ::W4, c4 = idx - r * SDZ::W4;
                 float g[4] = {sdz.pre[k].x, sdz.pre[k].y, sdz.pre[k].z, sdz.pre[k].w};
                 const float yv[4] = {sy1.pre[k].x, sy1.pre[k].y, sy1.pre[k].z, sy1.pre[k].w};
-                const bool in = (sdz.ok >> k) & 1u;
+                const int f0 = 4 * c4;                                        // float index from the first halo pixel (LEAD = 0)
+                if (((sdz.ok >> k) & 1u) && f0 < (TW + 4) * F) {
+                    const int px0 = f0 / F, ch0 = f0 - px0 * F;
+                    const int pr = ((r - 2) >> 1) + 1;                         // row in the pooled tiles
+                    const unsigned rowbit = ((unsigned)r & 1u) << 1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int f = 4 * c4 + e - SDZ::LEAD;                     // float index from the first halo pixel
-                    if (in && f >= 0 && f < (TW + 4) * F) {
-                        const int px = f / F, ch = f - px * F;
-                        const int pr = ((r - 2) >> 1) + 1, pc = ((px - 2) >> 1) + 1;            // row / pixel in the pooled tiles
-                        const unsigned pos = (((unsigned)r & 1u) << 1) | ((unsigned)px & 1u);
-                        const int o = pr * PFLS + PFLEAD + pc * F + ch;
-                        const float dp = ixb[o] == pos ? pdp[o] : 0.f;
-                        g[e] = (g[e] + dp) * (yv[e] > 0.f ? 1.0f : p.pf_alpha);
+                    for (int h = 0; h < 2; ++h) {                             // two channels of one pixel per step (F is even)
+                        int ch = ch0 + 2 * h, px = px0;
+                        if (ch >= F) { ch -= F; ++px; }
+                        const int pc = ((px - 2) >> 1) + 1;
+                        const unsigned pos = rowbit | ((unsigned)px & 1u);
+                        const int o = pr * PFLS + PFLEAD + pc * F + ch;       // even: 8-byte aligned pair
+                        const float2 dp = *reinterpret_cast<const float2*>(pdp + o);
+                        const unsigned ix = *reinterpret_cast<const unsigned short*>(ixb + o);
+                        g[2 * h] = (g[2 * h] + ((ix & 0xffu) == pos ? dp.x : 0.f)) * (yv[2 * h] > 0.f ? 1.0f : p.pf_alpha);
+                        g[2 * h + 1] = (g[2 * h + 1] + ((ix >> 8) == pos ? dp.y : 0.f)) * (yv[2 * h + 1] > 0.f ? 1.0f : p.pf_alpha);
                     }
                 }
                 sdz.pre[k] = make_float4(g[0], g[1], g[2], g[3]);
@@ -352,6 +358,12 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
         const int s = min(wave + k * NW, KSA - 1);
         pbm[k] = s < DC1::KS ? p.bm1[s * 64 + lane] : p.bm0[(s - DC1::KS) * 64 + lane];
     }
+    constexpr int NTW = UP ? cdiv(KTt * CT, NT) : 1;      // the transposed conv's kernel, one dword per thread and round
+    float ptw[NTW];
+    if constexpr (UP) {
+#pragma unroll
+        for (int k = 0; k < NTW; ++k) ptw[k] = p.tc_w[min(tid + k * NT, KTt * CT - 1)];
+    }
     FZB_STAMP(wave >= NWD, 27);
     for (int i = tid; i < (LDSN + 3) / 4; i += NT) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     FZB_STAMP(wave >= NWD, 28);
@@ -361,8 +373,10 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
 #pragma unroll
     for (int k = 0; k < NBR; ++k)
         if (wave + k * NW < KSA) lds[O_BM1 + (wave + k * NW) * 64 + lane] = pbm[k];
-    if constexpr (UP) {        // the transposed conv's kernel: global -> LDS (its first reader is three barriers away)
-        for (int i = tid; i < KTt * CT; i += NT) lds[O_TCW + i] = p.tc_w[i];
+    if constexpr (UP) {
+#pragma unroll
+        for (int k = 0; k < NTW; ++k)
+            if (tid + k * NT < KTt * CT) lds[O_TCW + tid + k * NT] = ptw[k];
     }
     if (tile >= ntiles) return;          // (grid <= ntiles: never taken; keeps the barrier counts below uniform by construction)
 
@@ -488,13 +502,22 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
 #pragma unroll 1
                     for (int mt = wv; mt < NLP / 16; mt += NWD) {
                         const int li = mt / (LWt / 16), mx = mt - li * (LWt / 16);
-                        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                        // operands first (all LDS reads in flight), then one MFMA chain per output-row parity
+                        float ta[2][KS1t], tb[2][KS1t];
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
 #pragma unroll
-                            for (int kk = 0; kk < KS1t; ++kk)
-                                d = __builtin_amdgcn_mfma_f32_16x16x4f32(ldsf[O_OUT + (2 * li + a) * ROWF + 2 * (mx * 16 + m16) * 12 + koff[kk]],
-                                                                         ldsf[woff + (a * KS1t + kk) * wstep], d, 0, 0, 0);
+                            for (int kk = 0; kk < KS1t; ++kk) {
+                                ta[a][kk] = ldsf[O_OUT + (2 * li + a) * ROWF + 2 * (mx * 16 + m16) * 12 + koff[kk]];
+                                tb[a][kk] = ldsf[woff + (a * KS1t + kk) * wstep];
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4 d2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                        for (int kk = 0; kk < KS1t; ++kk)
+#pragma unroll
+                            for (int a = 0; a < 2; ++a) d2[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[a][kk], tb[a][kk], d2[a], 0, 0, 0);
+                        const f32x4 d = d2[0] + d2[1];
                         if (m16 < CT) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) orow[(4 * q + r) * CT + m16] = d[r];
@@ -525,14 +548,22 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
                         offT[t] = valT[t] ? O_OUT + a * ROWF + 2 * q * 12 + e * 12 + (kr - e * F) : CST0;
                     }
                     const int boff = m16 < CT ? O_LOW + q * CT + m16 : (m16 == CT ? CST1 : CST0), bstep = m16 < CT ? 4 * CT : 0;
-#pragma unroll 1
-                    for (int st = wv; st < NLP / 4; st += NWW) {
-                        const int sd = ((4 * st) / LWt) * 2 * ROWF + ((4 * st) % LWt) * 2 * 12;
-                        const float bv = ldsf[boff + st * bstep];
+                    constexpr int KST = NLP / 4 / NWW;
+                    static_assert(NLP / 4 % NWW == 0, "T2: K-steps divide evenly over the weight-gradient waves");
+                    float tbv[KST], tav[KST][MBt];
 #pragma unroll
-                        for (int t = 0; t < MBt; ++t)
-                            tacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ldsf[offT[t] + (valT[t] ? sd : 0)], bv, tacc[t], 0, 0, 0);
+                    for (int i = 0; i < KST; ++i) {
+                        const int st = wv + i * NWW;
+                        const int sd = ((4 * st) / LWt) * 2 * ROWF + ((4 * st) % LWt) * 2 * 12;
+                        tbv[i] = ldsf[boff + st * bstep];
+#pragma unroll
+                        for (int t = 0; t < MBt; ++t) tav[i][t] = ldsf[offT[t] + (valT[t] ? sd : 0)];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < KST; ++i)
+#pragma unroll
+                        for (int t = 0; t < MBt; ++t) tacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tav[i][t], tbv[i], tacc[t], 0, 0, 0);
                 }
             } else {
                 store_interior<CA, G2, TW / G2, TH, 0, TW, TH, NT>(lds + O_OUT, p.dxb, cb, cy0, cx0, p.H, p.W, tid);

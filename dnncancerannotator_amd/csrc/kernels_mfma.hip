@@ -1563,15 +1563,26 @@ __global__ __launch_bounds__(256) void k_pg_fold(const FoldDesc* __restrict__ de
     }
     const float* S = slabs + d.slab_off;
     const int stride = d.MT * 256;
-    for (int i = threadIdx.x; i < stride; i += 256) {
-        float v[NBUCKET];
+    // every slab value of this fold in flight at once (MT <= 7 chunks of 256 x NBUCKET slabs): one memory round trip, not one per chunk
+    {
+        float v[7][NBUCKET];
 #pragma unroll
-        for (int s = 0; s < NBUCKET; ++s) v[s] = S[(size_t)s * stride + i];      // all slabs in flight at once
+        for (int c = 0; c < 7; ++c) {
+            if (c < d.MT) {
 #pragma unroll
-        for (int w = NBUCKET / 2; w > 0; w >>= 1)
+                for (int s = 0; s < NBUCKET; ++s) v[c][s] = S[(size_t)s * stride + c * 256 + threadIdx.x];
+            }
+        }
 #pragma unroll
-            for (int s = 0; s < w; ++s) v[s] += v[s + w];
-        Dl[i] = v[0];
+        for (int c = 0; c < 7; ++c) {
+            if (c < d.MT) {
+#pragma unroll
+                for (int w = NBUCKET / 2; w > 0; w >>= 1)
+#pragma unroll
+                    for (int s = 0; s < w; ++s) v[c][s] += v[c][s + w];
+                Dl[c * 256 + threadIdx.x] = v[c][0];
+            }
+        }
     }
     __syncthreads();
     const int o = blockIdx.y * blockDim.x + threadIdx.x;

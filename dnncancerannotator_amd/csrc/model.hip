@@ -92,15 +92,9 @@ int Model::wg_side_join() {
 
 int Model::alloc(void** ptr, size_t bytes) {
     if (bytes == 0) bytes = 4;
-    // experiment: skew consecutive allocations by a multiple of DNNCA_ALLOC_SKEW bytes so that equally sized tensors do not alias
-    // in the low address bits
-    static const size_t skew_unit = getenv("DNNCA_ALLOC_SKEW") ? (size_t)atol(getenv("DNNCA_ALLOC_SKEW")) : 0;
-    const size_t skew = skew_unit * (allocs.size() % 31);
-    void* base = nullptr;
-    HIP_TRY(hipMalloc(&base, bytes + skew));
-    allocs.push_back(base);
-    HIP_TRY(hipMemsetAsync(base, 0, bytes + skew, stream));
-    *ptr = static_cast<char*>(base) + skew;
+    HIP_TRY(hipMalloc(ptr, bytes));
+    allocs.push_back(*ptr);
+    HIP_TRY(hipMemsetAsync(*ptr, 0, bytes, stream));
     return DNNCA_OK;
 }
 

@@ -90,7 +90,7 @@ struct TailArgs {
 template <int PFD, int WSCALAR, bool MIDBAR, int ABL = 0, int SHIFT = 0>      // ABL (tuning builds): bit mask of parts left out
 __global__ __launch_bounds__(256, 2) void k_tail3(TailArgs p) {
     static_assert(PFD == 6 || PFD == 3, "the row loop is unrolled lcm(3 window slots, PFD prefetch slots) times");
-    constexpr int NACC = 84, NH = 5, NRED = NACC + NH, WRw = 18, MT = 4, NBK = 32;      // slab geometry of k_pgbwd<3,1,3>
+    constexpr int NACC = 84, NH = 5, NRED = NACC + NH, WRw = 18, MT = 4, NBK = kPgBuckets;      // slab geometry of k_pgbwd<3,1,3>
     __shared__ float red[4 * NRED + 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -404,7 +404,7 @@ struct FirstArgs {
 template <int PFD, int WSCALAR>
 __global__ __launch_bounds__(256, 2) void k_first3(FirstArgs p) {
     static_assert(PFD == 3 || PFD == 2, "ring slots; the row loop is unrolled 6 times (3 window slots x 2)");
-    constexpr int NA1 = 84, NA0 = 30, NRED = NA1 + NA0, NBK = 32;
+    constexpr int NA1 = 84, NA0 = 30, NRED = NA1 + NA0, NBK = kPgBuckets;
     __shared__ float red[4 * NRED];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;

@@ -471,7 +471,7 @@ def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
 
 
 @pytest.mark.parametrize('B, H, W, strip', [(2, 40, 128, True), (8, 16, 256, True), (2, 40, 128, False), (8, 16, 256, False),
-                                            (3, 24, 200, True), (1, 72, 64, True), (2, 64, 256, True)])
+                                            (3, 24, 200, True), (1, 72, 64, True), (2, 64, 256, True), (2, 64, 256, 'per-layer backward')])
 def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypatch, B, H, W, strip):
     """configs/unet.yaml, the vector-ALU kernels of the full-resolution 3-channel level against the float64 oracle, every variable on
     its own scale.  strip: the column-strip kernels (strip_dev.h; strips of 60 columns, row chunks; shapes with partial strips, one
@@ -481,7 +481,12 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
     tile kernel k_bwd3v (plain / with the pool fold); the (8, 16, 256) shape has a tile count divisible by 8 (XCD-aware order).
     (2, 64, 256) is made of whole tiles at every level: there the transposed convs' backward rides in the launch of the two-source
     conv behind them on all three levels (k_pgbwd TCF / TCM) and the 12 -> 6 transposed conv's forward in the fused 12-channel
-    decoder block (k_fz_up)."""
+    decoder block (k_fz_up); by default the 6- and 12-channel blocks' backward passes are the block-fused launches of
+    kernels_fused_bwd.hip (k_fzb), so the shape runs a second time with DNNCA_NO_FUSED_BWD for the per-layer TCM kernels."""
+    per_layer_bwd = strip == 'per-layer backward'
+    if per_layer_bwd:
+        monkeypatch.setenv('DNNCA_NO_FUSED_BWD', '1')
+        strip = True
     if not strip:
         monkeypatch.setenv('DNNCA_NO_TAIL3', '1')
         monkeypatch.setenv('DNNCA_NO_FIRST3', '1')
@@ -503,10 +508,51 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
     Hp.assert_grads_per_tensor(spec, m.get_grads(), gref, 2e-5, floor=floor)
     plan = set(r[0] for r in m.plan())
     if (B, H, W) == (2, 64, 256):
-        assert {'pgbwd_tc_3x2_3', 'pgbwd_tc_6x2_6', 'pgbwd_tc_12x2_12', 'fz_up_tc_12_12'} <= plan and not any(k.startswith('tconv') for k in plan), plan
+        bwd = {'pgbwd_tc_6x2_6', 'pgbwd_tc_12x2_12', 'pgbwd_pool_12x1_12', 'pgbwd_pool_6x1_6'} if per_layer_bwd else \
+              {'fzb_up_6', 'fzb_up_12', 'fzb_down_6_12', 'fzb_down_3_6'}
+        assert ({'pgbwd_tc_3x2_3', 'fz_up_tc_12_12', 'fz_down_3_6', 'fz_down_6_12', 'pg_fold'} | bwd) <= plan and not any(k.startswith('tconv') for k in plan), plan
+        assert per_layer_bwd or not any(k.startswith('pgbwd_') and k != 'pgbwd_tc_3x2_3' for k in plan), plan
     assert ('tail3_3x1_3' if strip else 'bwd3v_3x1_3') in plan, plan
     if 'fz_down_1_3' in plan or 'first3_fwd' in plan:          # the fused first block records the pool's window positions
         assert ('first3_bwd' if strip else 'bwd3v_pool_3x1_3') in plan and 'pgbwd_w_1x1_3' not in plan or not strip, plan
+    m.close()
+
+
+@pytest.mark.parametrize('leaky', [0.0, 0.3])
+@pytest.mark.parametrize('B, H, W', [(2, 64, 256), (3, 32, 128), (1, 96, 128), (9, 32, 256)])
+def test_block_fused_backward_against_oracle(gpu, leaky, B, H, W):
+    """kernels_fused_bwd.hip: the whole backward of a Downsample / Upsample block (components.py:77-81, 158-166) of the 6- and
+    12-channel levels in one launch (k_fzb: second conv, first conv, transposed conv / max-pool; data-gradient and weight-gradient
+    waves) against the float64 oracle, every variable on its own scale.  Shapes: several tiles per block and image; one tile row per
+    image at the 12-channel level (every tile touches the top and the bottom edge); one tile column at the 6-channel level; more
+    images than XCDs with a tile count that is not a multiple of 8 (plain tile order).  LeakyReLU: the gradient of the first conv's
+    output is masked with a non-zero slope, so the ring of the LDS tile outside the image is zeroed explicitly; the pool fold then
+    keeps the per-layer kernels (its ReLU-only tie rule), so only the decoder blocks fuse."""
+    full = dict(UNET)
+    if leaky:
+        full['activation'] = {'class_name': 'LeakyReLU', 'config': {'alpha': leaky}}
+    spec = O.ModelSpec('unet', 1, **full)
+    params = Hp.perturbed_params(spec, np.float64)
+    # (seed: on some random inputs two values of a pooling window agree to float32 precision and the float64 oracle routes that
+    #  window's gradient to the other one -- with seed 17 the (9, 32, 256) LeakyReLU case is off by 2.9e-3 on the down2 tensors for
+    #  the generic kernels and for every tuned variant alike; this seed has no such window in any of the eight cases)
+    rng = np.random.default_rng(23)
+    x = rng.random((B, H, W, 1)).astype(np.float32)
+    y = (rng.random((B, H, W)) < 0.05).astype(np.float32)
+    cfg = dict(weight_mul=3.0)
+    loss, grads, logits, _ = O.loss_and_grads(spec, params, x.astype(np.float64), y, cfg, training=True)
+    m = gpu.DeviceModel('unet', 1, H, W, B, **UNET, **(dict(leaky_alpha=leaky) if leaky else {}))
+    m.set_params(O.flatten(spec, params))
+    out = m.train_step(x, y, 0.0, m.loss_cfg(**cfg))
+    assert abs(out.loss - loss) <= 1e-4 * max(1.0, abs(loss))
+    p32 = {n: v.astype(np.float32) for n, v in params.items()}
+    _, g32, _, _ = O.loss_and_grads(spec, p32, x, y, cfg, training=True)
+    gref, g32 = O.flatten(spec, grads), O.flatten(spec, g32).astype(np.float64)
+    floor = [10 * np.abs(g32[sl] - gref[sl]).max() for _, sl in Hp.tensor_slices(spec)]
+    Hp.assert_grads_per_tensor(spec, m.get_grads(), gref, 2e-5, floor=floor)
+    plan = set(r[0] for r in m.plan())
+    want = {'fzb_up_6', 'fzb_up_12'} | (set() if leaky else {'fzb_down_6_12', 'fzb_down_3_6'})
+    assert want <= plan, plan
     m.close()
 
 
@@ -536,10 +582,10 @@ def test_strip_kernels_match_the_per_layer_kernels(gpu, monkeypatch, B, H, W):
 
     l1, g1, p1, plan1 = run()
     for k in ('DNNCA_NO_TAIL3', 'DNNCA_NO_FIRST3', 'DNNCA_NO_FIRST3F', 'DNNCA_NO_UP3F', 'DNNCA_NO_TCF', 'DNNCA_NO_FOLD_ADAM', 'DNNCA_NO_PREP_RIDE',
-              'DNNCA_NO_TCONV_RIDE', 'DNNCA_NO_TCM'):
+              'DNNCA_NO_TCONV_RIDE', 'DNNCA_NO_TCM', 'DNNCA_NO_FUSED_BWD'):
         monkeypatch.setenv(k, '1')
     l0, g0, p0, plan0 = run()
-    fused = {'tail3_3x1_3', 'first3_fwd', 'up3_fwd'} | ({'fz_up_tc_12_12', 'pgbwd_tc_6x2_6', 'pgbwd_tc_12x2_12'} if W % 128 == 0 and H % 32 == 0 else set())
+    fused = {'tail3_3x1_3', 'first3_fwd', 'up3_fwd'} | ({'fz_up_tc_12_12', 'fzb_up_6', 'fzb_up_12', 'fzb_down_6_12', 'fzb_down_3_6'} if W % 128 == 0 and H % 32 == 0 else set())
     assert fused <= plan1 and not ((fused | {'first3_bwd'}) & plan0), (plan1, plan0)
     assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
     assert np.abs(np.asarray(p1) - np.asarray(p0)).max() <= 2e-5
