@@ -9,6 +9,14 @@ synthetic 512x512x1 batches, 8 slices per GPU, fp32, on N MI355X (weak scaling: 
 One process per GPU; gradients are summed by ONE RCCL all-reduce per step inside libdnnca (no torch in the workers:
 torch bundles its own ROCm runtime, which must not share a process with libdnnca).  The RCCL unique id travels through
 a file keyed by the launcher's pid.  Rank 0 prints one JSON line.
+
+The line's `value` is the headline configuration (BASELINE.json configs[1]).  At N = 1 the same run also times the other two
+single-GPU configurations of BASELINE.json (configs[2] unet_big bf16 B=4, configs[3] mulmo_unet f32 B=8) for a few steps each
+and reports them under `other_workloads` (informative, never `value`).  With fewer than 100 steps the timed region is repeated
+(`repeats`, `region_ms`) and the line carries the median region: `steps` / `ms_per_step` describe ONE region of exactly K steps.
+
+DNNCA_FORCE_COMM=1 rehearses the N > 1 sequence on one GPU: id exchange through the file, a one-rank RCCL communicator,
+barriers and the max-reduction of the wall time through it (tests/test_engine_gpu.py::test_rccl_one_rank_rehearsal).
 """
 
 import argparse
@@ -28,10 +36,8 @@ from dnncancerannotator_amd.synthetic import synthetic_batch         # noqa: E40
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec; 6.29 TB/s measured float4 copy)
 H = W = 512
-C = 1
-BATCH_PER_GPU = 8              # configs[1]: configs/unet.yaml, batch 8 512x512x1, fp32, 1 x MI355X
 UNET_YAML = dict(n_filters_first=3, n_downsample=3, rate=2, kernel_size=3, conv_stride=1, bn=False, padding='same')
-# the other single-GPU configurations of BASELINE.json (parity-test cases; `--workload` times them for DESIGN.md)
+# the single-GPU configurations of BASELINE.json: configs[1] is the metric's; [2] and [3] ride along under `other_workloads`
 WORKLOADS = {
     'unet': dict(arch='unet', C=1, batch=8, dtype='f32', opts=UNET_YAML, name='configs/unet.yaml'),
     'unet_big': dict(arch='unet', C=1, batch=4, dtype='bf16', name='configs/unet_big.yaml',
@@ -39,8 +45,7 @@ WORKLOADS = {
     'mulmo_unet': dict(arch='mulmo', C=3, batch=8, dtype='f32', name='configs/mulmo_unet.yaml',
                        opts=dict(n_filters_first=16, n_downsample=4, rate=2, kernel_size=3, conv_stride=1, bn=True, padding='same')),
 }
-
-
+PROF_STEPS = 5
 CPU_THREADS = 16               # the GPU box gives one GPU's job 16 host cores; numpy's BLAS pool is pinned to that many
 
 
@@ -79,53 +84,40 @@ def cpu_baseline(sample_steps=5):
             'c1_batch1': {'value': round(c1, 3), 'unit': 'slices/s', 'sample': '%d train steps of one 1x%dx%dx1 batch (C1)' % (2 * sample_steps, H, W)}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--generic', action='store_true', help='force the untuned generic kernels')
-    ap.add_argument('--workload', default='unet', choices=sorted(WORKLOADS), help='default: the metric\'s configuration (unet)')
-    args = ap.parse_args()
-
-    ctx = distributed.context()          # RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run (one process per GPU)
-    rank, local_rank, world = ctx.rank, ctx.local_rank, ctx.world
-    if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, world, args.gpus))
-    dev.init_device(local_rank)
-    wl = WORKLOADS[args.workload]
-    global C, BATCH_PER_GPU
-    C, BATCH_PER_GPU = wl['C'], wl['batch']
-    model = dev.DeviceModel(wl['arch'], C, H, W, BATCH_PER_GPU, force_generic=args.generic, dtype=wl['dtype'], **wl['opts'])
+def time_workload(wname, steps, warmup, ctx, comm, generic=False, repeats=1, host_leg=False):
+    """Builds the workload's model on this rank's GPU and times `repeats` regions of exactly `steps` train steps on a batch that is
+    resident in HBM, each region bracketed by a barrier + device synchronisation on both sides; the wall time of a region is the
+    maximum over the ranks.  Returns the fields of the JSON line that describe this workload (rank 0's view)."""
+    rank, world = ctx.rank, ctx.world
+    wl = WORKLOADS[wname]
+    C, B = wl['C'], wl['batch']
+    model = dev.DeviceModel(wl['arch'], C, H, W, B, force_generic=generic, dtype=wl['dtype'], **wl['opts'])
     model.init_glorot(seed=2)          # same weights on every rank (random-init weights of the named architecture)
-    if world > 1:                      # (one GPU: no communicator -- the single-replica step keeps its fused fold + Adam launch)
-        uid = distributed.exchange_unique_id(ctx, dev.DeviceModel)     # 128-byte RCCL id through a file keyed by the launcher's pid
+    if comm:                           # (one GPU, not forced: no communicator -- the single-replica step keeps its fused fold + Adam launch)
+        uid = distributed.exchange_unique_id(ctx, dev.DeviceModel, force=True, tag=wname)     # 128-byte RCCL id through a file keyed by the launcher's pid
         model.comm_init(rank, world, uid)
 
     # rank-local shard of the global batch, resident in HBM before the timed region
-    x, y = synthetic_batch(BATCH_PER_GPU, H, W, C, seed_x=100 + rank, seed_y=200 + rank)
+    x, y = synthetic_batch(B, H, W, C, seed_x=100 + rank, seed_y=200 + rank)
     xb, yb = dev.DeviceBuffer(x), dev.DeviceBuffer(y)
     cfg = model.loss_cfg(weight_mul=3.0)            # configs/additionals/deploy_options.yaml:5-7
     lr = 1e-3
 
     def barrier():
         model.sync()
-        if world > 1:
+        if comm:
             model.comm_allreduce([0.0])
         model.sync()
 
-    for _ in range(args.warmup):
-        model.train_step_dev(xb, yb, BATCH_PER_GPU, lr, cfg)
+    for _ in range(warmup):
+        model.train_step_dev(xb, yb, B, lr, cfg)
     model.sync()
 
-    # which kernel dominates?  two fully instrumented steps outside the timed region
+    # which kernel dominates?  a few fully instrumented steps outside the timed region
     model.profile_reset()
     model.profile_enable(1)
-    PROF_STEPS = 5
     for _ in range(PROF_STEPS):
-        model.train_step_dev(xb, yb, BATCH_PER_GPU, lr, cfg)
+        model.train_step_dev(xb, yb, B, lr, cfg)
     model.sync()
     full_table = list(model.profile())
     # (only kernels that move data or compute: under a profiler the bracket of a bookkeeping launch can absorb one-off costs)
@@ -138,26 +130,33 @@ def main():
     # costs ~3 us of dispatch: bracketing every launch would take 1.5 % off `value`)
     model.profile_enable(2, focus=dominant, period=4)
 
-    barrier()
-    t0 = time.perf_counter()
-    model.timer_start()
-    for _ in range(args.steps):
-        model.train_step_dev(xb, yb, BATCH_PER_GPU, lr, cfg)
-    ev_ms = model.timer_stop()
-    barrier()
-    wall = time.perf_counter() - t0
-    elapsed = float(model.comm_allreduce([wall], op='max')[0]) if world > 1 else wall
+    regions, ev_regions = [], []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        model.timer_start()
+        for _ in range(steps):
+            model.train_step_dev(xb, yb, B, lr, cfg)
+        ev_ms = model.timer_stop()
+        barrier()
+        wall = time.perf_counter() - t0
+        regions.append(float(model.comm_allreduce([wall], op='max')[0]) if comm else wall)
+        ev_regions.append(ev_ms)
     out = model.last_step_out()
     prof = {r[0]: r for r in model.profile()}
     model.profile_enable(0)
 
+    res = None
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * BATCH_PER_GPU * args.steps / elapsed
-        name, launches, total_ms, bytes_per, flops_per = prof.get(dominant, table[0])      # (table[0]: the two instrumented steps)
+        order = sorted(range(repeats), key=lambda i: regions[i])
+        mid = order[repeats // 2]                    # the median region (repeats is odd or 1)
+        elapsed = regions[mid]
+        ms_per_step = 1e3 * elapsed / steps
+        value = world * B * steps / elapsed
+        name, launches, total_ms, bytes_per, flops_per = prof.get(dominant, table[0])      # (table[0]: the instrumented steps)
         avg_ms = total_ms / max(launches, 1)
         mfma_peak = 2500.0 if wl['dtype'] == 'bf16' else 157.3        # TFLOP/s dense, MI355X_MICROARCH.md:42-43
-        if args.workload == 'unet':          # HBM-bound (AI ~ 9 FLOP/B): algorithmic bytes of the launch / its duration
+        if wname == 'unet':                  # HBM-bound (AI ~ 9 FLOP/B): algorithmic bytes of the launch / its duration
             bound, unit, peak = 'hbm', 'GB/s', HBM_PEAK_GBS
             achieved = bytes_per / (avg_ms * 1e-3) / 1e9
         else:                                 # dense contractions: algorithmic FLOPs / duration against the MFMA peak
@@ -184,17 +183,14 @@ def main():
         step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
-        if os.path.exists(tpath) and args.workload == 'unet':
+        if os.path.exists(tpath) and wname == 'unet':
             with open(tpath) as f:
                 traffic = json.load(f).get(dominant)
-        line = {
-            'metric': 'MRI slices/sec (fwd+bwd) %s 512x512 bs=%d' % (args.workload, BATCH_PER_GPU), 'value': round(value, 2), 'unit': 'slices/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
-            'config': {'workload': '%s train step (fwd + weighted BCE + bwd + Adam), batch %d x 512x512x%d '
-                                   'per GPU, %s, random-init weights' % (wl['name'], BATCH_PER_GPU, C, wl['dtype']),
-                       'global_batch': world * BATCH_PER_GPU, 'parallelism': 'dp%d' % world,
-                       'kernels': 'generic' if args.generic else 'tuned'},
+        res = {
+            'value': round(value, 2), 'ms_per_step': round(ms_per_step, 4), 'dtype': wl['dtype'], 'batch': B, 'channels': C,
+            'workload': '%s train step (fwd + weighted BCE + bwd + Adam), batch %d x 512x512x%d per GPU, %s, random-init weights'
+                        % (wl['name'], B, C, wl['dtype']),
+            'repeats': repeats, 'region_ms': [round(1e3 * r, 3) for r in regions],
             'roofline': {'bound': bound, 'kernel': dominant, 'achieved': round(achieved, 1), 'peak': peak,
                          'unit': unit, 'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'launches': int(launches), 'avg_launch_us': round(avg_ms * 1e3, 2),
@@ -206,35 +202,89 @@ def main():
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(step_gbs / HBM_PEAK_GBS, 4),
                               'launches_per_step': round(sum(r[1] for r in full_table) / PROF_STEPS, 1)},
             'roofline_all': roofline_all,
-            'hip_event_ms_per_step': round(ev_ms / args.steps, 4),
+            'hip_event_ms_per_step': round(ev_regions[mid] / steps, 4),
             'final_loss': round(float(out.loss), 6),
         }
-        if world == 1 and args.workload == 'unet':
+        if host_leg:
             # informative, never `value`: the same steps with every batch starting in (pageable) host memory -- uploads into the
             # model's staging ring on the copy stream, step scalars read one step late (tools/e2e_rate.py)
             ring = model.staging()
-            hb = [synthetic_batch(BATCH_PER_GPU, H, W, C, seed_x=300 + i, seed_y=400 + i) for i in range(2)]
-            n_host, prev = max(20, args.steps // 2), None
+            hb = [synthetic_batch(B, H, W, C, seed_x=300 + i, seed_y=400 + i) for i in range(2)]
+            n_host, prev = max(20, steps // 2), None
             model.sync()
             th = time.perf_counter()
             for i in range(n_host):
                 slot = i % ring.slots
                 px, py = ring.upload(slot, hb[i % 2][0], hb[i % 2][1], wait=False)
-                ring.train_step(slot, px, py, BATCH_PER_GPU, lr, cfg)
+                ring.train_step(slot, px, py, B, lr, cfg)
                 if prev is not None:
                     ring.out(prev)
                 prev = slot
             ring.out(prev)
             th = time.perf_counter() - th
-            line['from_host_memory'] = {'value': round(BATCH_PER_GPU * n_host / th, 1), 'unit': 'slices/s', 'steps': n_host,
-                                        'ms_per_step': round(1e3 * th / n_host, 4),
-                                        'note': 'PCIe-inclusive: %.1f MB per step from pageable host arrays through the staging ring'
-                                                % ((hb[0][0].nbytes + hb[0][1].nbytes) / 1e6)}
+            res['from_host_memory'] = {'value': round(B * n_host / th, 1), 'unit': 'slices/s', 'steps': n_host,
+                                       'ms_per_step': round(1e3 * th / n_host, 4),
+                                       'note': 'PCIe-inclusive: %.1f MB per step from pageable host arrays through the staging ring'
+                                               % ((hb[0][0].nbytes + hb[0][1].nbytes) / 1e6)}
+    model.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-workloads', action='store_true', help='skip the informative unet_big / mulmo_unet legs')
+    ap.add_argument('--generic', action='store_true', help='force the untuned generic kernels')
+    ap.add_argument('--workload', default='unet', choices=sorted(WORKLOADS), help='default: the metric\'s configuration (unet)')
+    args = ap.parse_args()
+
+    ctx = distributed.context()          # RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run (one process per GPU)
+    rank, local_rank, world = ctx.rank, ctx.local_rank, ctx.world
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    dev.init_device(local_rank)
+    # N > 1: the communicator; DNNCA_FORCE_COMM=1: the same sequence on one rank (rehearsal: a sum over one rank is the identity)
+    force_comm = world == 1 and os.environ.get('DNNCA_FORCE_COMM') == '1'
+    if force_comm:
+        os.environ['DNNCA_FORCE_RCCL'] = '1'
+    comm = world > 1 or force_comm
+    repeats = 1 if args.steps >= 100 else 3
+    wl = WORKLOADS[args.workload]
+    head = time_workload(args.workload, args.steps, args.warmup, ctx, comm, generic=args.generic, repeats=repeats,
+                         host_leg=(world == 1 and args.workload == 'unet' and not comm))
+    if rank == 0:
+        line = {
+            'metric': 'MRI slices/sec (fwd+bwd) %s 512x512 bs=%d' % (args.workload, wl['batch']), 'value': head['value'], 'unit': 'slices/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
+            'config': {'workload': head['workload'], 'global_batch': world * wl['batch'], 'parallelism': 'dp%d' % world,
+                       'kernels': 'generic' if args.generic else 'tuned', 'communicator': bool(comm)},
+        }
+        for k in ('repeats', 'region_ms', 'roofline', 'roofline_step', 'roofline_all', 'hip_event_ms_per_step', 'final_loss', 'from_host_memory'):
+            if k in head:
+                line[k] = head[k]
+    if world == 1 and not comm and args.workload == 'unet' and not args.generic and not args.no_other_workloads:
+        # BASELINE.json configs[2] and [3], a few steps each (informative; the model of the headline leg is closed by now)
+        others = {}
+        n_other = max(5, args.steps // 4)
+        for wname in ('unet_big', 'mulmo_unet'):
+            r = time_workload(wname, n_other, max(3, args.warmup // 2), ctx, False)
+            owl = WORKLOADS[wname]
+            others[wname] = {'metric': 'MRI slices/sec (fwd+bwd) %s 512x512 bs=%d' % (wname, owl['batch']), 'value': r['value'], 'unit': 'slices/s',
+                             'ms_per_step': r['ms_per_step'], 'steps': n_other, 'dtype': r['dtype'], 'workload': r['workload'],
+                             'roofline': {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'share_of_step')},
+                             'roofline_step': r['roofline_step'],
+                             'top_kernels': r['roofline_all'][:6]}
+        line['other_workloads'] = others
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == 'unet':
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     distributed.cleanup(ctx)
-    model.close()
 
 
 if __name__ == '__main__':

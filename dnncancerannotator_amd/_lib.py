@@ -133,6 +133,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError('%s is missing: run `python -m dnncancerannotator_amd.build` (hipcc, gfx950). '
                           'There is no CPU fallback.' % LIB_PATH)
+    # Multi-process GPU work on this platform needs dmabuf IPC: with the legacy mode RCCL's communicator set-up fails with
+    # `hipIpcGetMemHandle: invalid argument` (the host driver only supports dmabuf).  The ROCm runtime reads the variable when it
+    # initialises, i.e. at the first HIP call behind this dlopen -- so this is the ONE place every process of the package passes
+    # through in time: workers of `python -m dnncancerannotator_amd.launch`, ranks started by torch.distributed.run (bench.py),
+    # single-GPU runs.  A value the caller exported wins.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -195,7 +195,7 @@ struct BArgs {
 
 // UP:   CA == F; NSRC = 2; the first conv's data gradient has 2F channels = NPASS passes of 12 ([up | skip])
 // DOWN: CA = the block's input channels; NSRC = 1
-template <bool UP, int CA, int F, int TW, int NT, int ISSUE_DG = 1, int ISSUE_WG = 3>
+template <bool UP, int CA, int F, int TW, int NT, int ISSUE_DG = 2, int ISSUE_WG = 3>
 __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
     constexpr int TH = 8, NW = NT / 64, NWD = NW / 2, NWW = NW - NWD, NSRC = UP ? 2 : 1, CT = 12;
     constexpr int KID = (UP ? 0 : 2) + (F == 12 ? 1 : 0);      // tuning builds: which stamp table
@@ -576,6 +576,10 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
             cb = b; cx0 = x0; cy0 = y0;
             commit();
             tile += gridDim.x;
+            // nothing of this tile is pending when the next one starts: without this the next prefetch's address arithmetic, which reuses
+            // the registers the tile's global stores were fed from, waits for those stores at the top of P1 (the builtin, not an asm
+            // wait: hipcc's counter bookkeeping must see it)
+            if constexpr (DG) __builtin_amdgcn_s_waitcnt(0x0070);
             lds_barrier();
             FZB_STAMP(!DG, it < 3 ? 10 + 8 * it : 99);
         }

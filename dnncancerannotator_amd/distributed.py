@@ -25,23 +25,30 @@ def context(environ=None):
     return Context(rank, local_rank, world, key)
 
 
-def rendezvous_path(ctx):
-    return os.path.join(os.environ.get('TMPDIR', '/tmp'), 'dnnca_rdzv_%s.id' % ctx.rdzv_key)
+def rendezvous_path(ctx, tag=''):
+    return os.path.join(os.environ.get('TMPDIR', '/tmp'), 'dnnca_rdzv_%s%s.id' % (ctx.rdzv_key, '_' + tag if tag else ''))
 
 
-def exchange_unique_id(ctx, id_source, timeout=300.0):
+_published = []          # rendezvous files this process wrote (rank 0): removed by cleanup()
+
+
+def exchange_unique_id(ctx, id_source, timeout=300.0, force=False, tag=''):
     """Rank 0 creates the RCCL unique id (`id_source.comm_unique_id()`) and publishes it atomically in a file named
-    after the launcher; the other ranks poll for it.  Returns the id bytes (None when world == 1)."""
-    if ctx.world == 1:
+    after the launcher; the other ranks poll for it.  Returns the id bytes (None when world == 1, unless `force`: the
+    one-rank rehearsal of the same path -- rank 0 then reads its own file back).  `tag` keeps several communicators of
+    one job apart."""
+    if ctx.world == 1 and not force:
         return None
-    path = rendezvous_path(ctx)
+    path = rendezvous_path(ctx, tag)
     if ctx.rank == 0:
         uid = id_source.comm_unique_id()
         tmp = '%s.tmp%d' % (path, os.getpid())
         with open(tmp, 'wb') as f:
             f.write(uid)
         os.replace(tmp, path)
-        return uid
+        _published.append(path)
+        if ctx.world > 1:
+            return uid
     t0 = time.time()
     while True:
         try:
@@ -58,9 +65,11 @@ def exchange_unique_id(ctx, id_source, timeout=300.0):
 
 
 def cleanup(ctx):
-    if ctx.world > 1 and ctx.rank == 0:
+    paths = list(_published) + ([rendezvous_path(ctx)] if ctx.world > 1 and ctx.rank == 0 else [])
+    del _published[:]
+    for path in paths:
         try:
-            os.remove(rendezvous_path(ctx))
+            os.remove(path)
         except OSError:
             pass
 

@@ -48,8 +48,8 @@ def main(argv=None, module='dnncancerannotator_amd'):
     key = uuid.uuid4().hex
     procs = []
     for rank in range(args.nproc):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.nproc), DNNCA_RDZV_KEY=key,
-                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        # (HSA_ENABLE_IPC_MODE_LEGACY=0, which RCCL needs here, is set by _lib.load() in every worker before the first HIP call)
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.nproc), DNNCA_RDZV_KEY=key)
         procs.append(subprocess.Popen([sys.executable, '-m', module] + args.rest, env=env))
     return supervise(procs)
 

@@ -620,6 +620,28 @@ def test_rccl_one_rank_rehearsal(gpu):
     assert out['red_big'] is True          # 5000 doubles > 2^40 through the chunked host all-reduce, exact
 
 
+def test_bench_n_gt_1_sequence_on_one_rank(gpu):
+    """bench.py's N > 1 branch on one GPU (DNNCA_FORCE_COMM=1): the RCCL unique id through the rendezvous file, a one-rank
+    communicator, barriers and the max-reduction of the region's wall time through it, the data-parallel launch sequence (slab
+    fold, ncclAllReduce of [gradients, loss], Adam with 1/world) in every timed step -- and the line still parses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DNNCA_FORCE_COMM='1')
+    env.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)          # _lib.load() must provide it
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '2', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['steps'] == 5 and line['config']['communicator'] is True
+    assert line['repeats'] == 3 and len(line['region_ms']) == 3
+    assert line['value'] > 1000 and abs(line['value'] - 8 * 5 / (line['ms_per_step'] * 5e-3)) <= 0.01 * line['value']
+    names = [k['kernel'] for k in line['roofline_all']]
+    assert 'pg_fold' in names and 'g_adam' in names and 'pg_fold_adam' not in names, names      # the data-parallel sequence ran
+    assert 'other_workloads' not in line and 'from_host_memory' not in line
+
+
 def test_bucketed_gradient_allreduce_rehearsal(gpu):
     """Gradient vectors above 1 MB (unet_big 63 MB, mulmo_unet 6.9 MB) are all-reduced in buckets on a second stream while
     the backward pass runs (reverse layer order: the backward pass finalises the flat gradient vector from its end).  On a
