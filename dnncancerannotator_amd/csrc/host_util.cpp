@@ -14,7 +14,6 @@
 namespace {
 
 uint32_t table[4][256];
-bool table_ready = false;
 
 void make_table() {
     for (uint32_t i = 0; i < 256; ++i) {
@@ -24,12 +23,12 @@ void make_table() {
     }
     for (uint32_t i = 0; i < 256; ++i)
         for (int t = 1; t < 4; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
-    table_ready = true;
 }
 
 // portable slicing-by-4 (hosts without SSE4.2)
 uint32_t crc_sw(uint32_t c, const unsigned char* p, size_t n) {
-    if (!table_ready) make_table();
+    static const bool ready = (make_table(), true);      // function-local static: built once, thread-safe (reader threads)
+    (void)ready;
     while (n >= 4) {
         uint32_t w;
         memcpy(&w, p, 4);

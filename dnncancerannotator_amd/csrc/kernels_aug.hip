@@ -7,6 +7,7 @@
 // in two launches over a uint8 batch that was uploaded as stored (a quarter of the float bytes over PCIe).  The random draws are
 // made by the host (augment.py) and passed per image, so the arithmetic is checkable against the oracle draw for draw.
 // random_warp (tfa.image.sparse_image_warp) follows below as dnnca_warp_f32.
+#include <string.h>
 #include "fast.h"
 #include "kernels.h"
 
@@ -125,7 +126,26 @@ int dnnca_augment_u8(void* model, const void* src_dev, int batch, int hs, int ws
     a.x = x_dev; a.y = y_dev;
     a.B = batch; a.Hs = hs; a.Ws = ws; a.Cs = cs; a.Ho = ho; a.Wo = wo; a.label_index = label_index;
     a.contrast_mask = contrast_mask & ~(1u << label_index);
-    HIP_TRY(hipMemcpyAsync((void*)a.prm, params_host, (size_t)batch * sizeof(dnnca_aug_param), hipMemcpyHostToDevice, M->stream));
+    // the draws travel through a pinned row of the model's ring: the caller's buffer is free when this call returns, and the call
+    // does not wait for the stream (a row is only waited for when it comes round again, four calls later)
+    const size_t prm_bytes = (size_t)batch * sizeof(dnnca_aug_param);
+    if (prm_bytes > M->aug_pin_bytes) {
+        HIP_TRY(hipStreamSynchronize(M->stream));         // uploads from the old rows are complete
+        if (M->aug_pin) (void)hipHostFree(M->aug_pin);
+        M->aug_pin = nullptr;
+        M->aug_pin_bytes = 0;
+        const size_t row = (size_t)M->desc.max_batch * sizeof(dnnca_aug_param) > prm_bytes ? (size_t)M->desc.max_batch * sizeof(dnnca_aug_param) : prm_bytes;
+        HIP_TRY(hipHostMalloc(&M->aug_pin, row * Model::kAugRing, hipHostMallocDefault));
+        M->aug_pin_bytes = row;
+    }
+    const int k = M->aug_k;
+    M->aug_k = (k + 1) % Model::kAugRing;
+    if (!M->aug_ev[k]) HIP_TRY(hipEventCreateWithFlags(&M->aug_ev[k], hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(M->aug_ev[k]));
+    char* pin = (char*)M->aug_pin + (size_t)k * M->aug_pin_bytes;
+    memcpy(pin, params_host, prm_bytes);
+    HIP_TRY(hipMemcpyAsync((void*)a.prm, pin, prm_bytes, hipMemcpyHostToDevice, M->stream));
+    HIP_TRY(hipEventRecord(M->aug_ev[k], M->stream));
     HIP_TRY(hipMemsetAsync(a.sums, 0, (size_t)batch * cs * 4, M->stream));
     const int n = ho * wo;
     int bx = (n + 256 * 16 - 1) / (256 * 16);
@@ -134,7 +154,6 @@ int dnnca_augment_u8(void* model, const void* src_dev, int batch, int hs, int ws
         LAUNCH(M, "aug_sums", (double)batch * n * cs, 0, hipLaunchKernelGGL(k_aug_sums, dim3(bx, batch), dim3(256), 0, M->stream, a));
     LAUNCH(M, "aug_apply", (double)batch * n * (cs + 4.0 * cs), 0,
            hipLaunchKernelGGL(k_aug_apply, dim3((unsigned)(((size_t)batch * n + 255) / 256)), dim3(256), 0, M->stream, a));
-    HIP_TRY(hipStreamSynchronize(M->stream));        // params_host may be released by the caller
     return DNNCA_OK;
 }
 

@@ -83,6 +83,13 @@ struct Model {
     size_t warp_scratch_bytes = 0;
     void* aug_scratch = nullptr;         // per-image augmentation draws + channel sums (kernels_aug.hip)
     size_t aug_scratch_bytes = 0;
+    // the caller's draws wait for their asynchronous upload in a small ring of pinned rows, so that dnnca_augment_u8 returns
+    // without synchronising the stream (the exam-file train loop keeps a step queued behind the running one)
+    static constexpr int kAugRing = 4;
+    void* aug_pin = nullptr;             // kAugRing x aug_pin_bytes, pinned
+    size_t aug_pin_bytes = 0;
+    hipEvent_t aug_ev[kAugRing] = {nullptr, nullptr, nullptr, nullptr};      // recorded behind the upload that read row k
+    int aug_k = 0;
     float* first_slabs = nullptr;        // bucket copies of the first-layer weight gradient (kernels_first.hip; kept zeroed)
     void* bn_part = nullptr;             // partials table of the tuned BN reductions (kernels_misc.hip)
     size_t bn_part_bytes = 0;

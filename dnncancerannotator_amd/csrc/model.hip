@@ -50,6 +50,9 @@ Model::~Model() {
     }
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (out_ring) (void)hipHostFree(out_ring);
+    if (aug_pin) (void)hipHostFree(aug_pin);
+    for (auto e : aug_ev)
+        if (e) (void)hipEventDestroy(e);
     if (wg_fork) (void)hipEventDestroy(wg_fork);
     if (wg_join) (void)hipEventDestroy(wg_join);
     if (wg_bucket) (void)hipEventDestroy(wg_bucket);

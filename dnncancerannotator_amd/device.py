@@ -315,7 +315,22 @@ class DeviceModel:
                                        fptr(prob) if return_prob else None))
         return (out, prob) if return_prob else out
 
+    def check_dev(self, xbuf, ybuf, batch):
+        """Device-resident (x, y) that carry their shapes (DeviceBuffer, DeviceView) must match the built model: the staged and the
+        *_dev entry points take bare pointers, a mismatched batch would be read as misaligned memory (the host entry points check in
+        _check_x).  Raises ValueError like them."""
+        xs, ys = getattr(xbuf, 'shape', None), getattr(ybuf, 'shape', None)
+        if xs is None:
+            return
+        if len(xs) != 4 or tuple(xs[1:]) != self.in_shape:
+            raise ValueError('x shape %s does not match the built input %s' % (tuple(xs), ('B',) + self.in_shape))
+        if ys is not None and tuple(ys) != tuple(xs[:3]):
+            raise ValueError('y shape %s does not match x %s' % (tuple(ys), tuple(xs)))
+        if not 1 <= int(batch) <= min(int(xs[0]), self.max_batch):
+            raise ValueError('batch %d outside [1, %d]' % (batch, min(int(xs[0]), self.max_batch)))
+
     def train_step_dev(self, xbuf, ybuf, batch, lr, cfg, want_out=False):
+        self.check_dev(xbuf, ybuf, batch)
         out = _lib.StepOut() if want_out else None
         check(self.lib.dnnca_train_step_dev(self.handle, xbuf.ptr, ybuf.ptr, int(batch), float(lr), C.byref(cfg),
                                             C.byref(out) if want_out else None))
@@ -373,13 +388,18 @@ class DeviceModel:
         if not hasattr(self, '_aug'):
             self._aug = (RawDeviceBuffer(), RawDeviceBuffer(), RawDeviceBuffer())
         src, xb, yb = self._aug
-        if src_ptr is None:
+        own_upload = src_ptr is None
+        if own_upload:
             src.upload(raw)
             src_ptr = src.ptr
         xb.reserve(B * ho * wo * (cs - 1) * 4)
         yb.reserve(B * ho * wo * 4)
         prm = (_lib.AugParam * B)(*[_lib.AugParam(int(p[0]), int(p[1]), int(p[2]), float(p[3])) for p in params])
         check(self.lib.dnnca_augment_u8(self.handle, src_ptr, B, hs, ws, cs, int(label_index), mask, prm, ho, wo, xb.ptr, yb.ptr))
+        if own_upload:
+            # dnnca_augment_u8 is asynchronous on the model's stream (a staged batch keeps the loop one step ahead); the batch this
+            # call uploaded itself lives in a buffer the next call overwrites with a blocking copy, so here the stream is drained
+            self.sync()
         return DeviceView(xb, (B, ho, wo, cs - 1)), DeviceView(yb, (B, ho, wo))
 
     def warp(self, xv, yv, ctrl, wv):

@@ -287,6 +287,7 @@ class TFKerasModel:
                     xb, yb = dm.augment_u8(shard(batch.raw)[0], params, batch.output_size, batch.label_index, src_ptr=src)
                     if batch.warp is not None:
                         xb, yb = dm.warp(xb, yb, shard(batch.warp[0])[0], shard(batch.warp[1])[0])
+                    dm.check_dev(xb, yb, n)
                     feeder.ring.train_step(slot, xb.ptr, yb.ptr, n, self.learning_rate, cfg)
                 else:
                     batch = item[1]
@@ -426,6 +427,7 @@ class TFKerasModel:
                     ring.wait(slot)
                     xv, yv = dm.augment_u8(shard(batch.raw)[0], augment.plain_params(n), batch.output_size, batch.label_index,
                                            contrast_channels=(), src_ptr=src)
+                    dm.check_dev(xv, yv, n)
                     px, py = xv.ptr, yv.ptr
                 else:
                     _, slot, px, py, n = item

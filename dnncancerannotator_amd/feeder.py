@@ -39,7 +39,7 @@ class BatchFeeder:
         self.free = queue.Queue()
         for s in slots:
             self.free.put(s)
-        self.ready = queue.Queue(maxsize=len(slots))
+        self.ready = queue.Queue(maxsize=max(1, len(slots)))      # bounded even without slots of its own: 'host' elements are whole batches
         self._first = first
         self._stop = False
         self.thread = threading.Thread(target=self._run, name='dnnca-batch-feeder', daemon=True)
@@ -58,7 +58,10 @@ class BatchFeeder:
             return ('host', batch)
         if isinstance(batch, augment.RawBatch):
             raw = np.ascontiguousarray(self.shard(batch.raw)[0], np.uint8)
-            if not len(raw) or not self.ring.fits(raw):
+            # a batch the model cannot take as it is -- too large for a slot or for max_batch, or cropped to another size than the
+            # built input -- goes to the loop unstaged: its host path chunks it or raises the shape error (never a silent misread)
+            if (not len(raw) or not self.ring.fits(raw) or len(raw) > self.dm.max_batch or raw.ndim != 4 or
+                    tuple(int(v) for v in batch.output_size) != tuple(self.dm.in_shape[:2]) or raw.shape[-1] - 1 != self.dm.in_shape[2]):
                 return ('host', batch)
             slot = self.free.get()
             if slot is None:
@@ -67,8 +70,9 @@ class BatchFeeder:
             return ('raw', slot, src, batch, len(raw))
         x, y = self.shard(np.asarray(batch[0]), np.asarray(batch[1]))
         x, y = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32)
-        if not len(x) or not self.ring.fits(x, y) or len(x) > self.dm.max_batch:
-            return ('host', batch)
+        if (not len(x) or not self.ring.fits(x, y) or len(x) > self.dm.max_batch or x.ndim != 4 or
+                tuple(x.shape[1:]) != tuple(self.dm.in_shape) or y.shape != x.shape[:3]):
+            return ('host', batch)        # (a shape the built model does not have: DeviceModel._check_x raises on the host path)
         slot = self.free.get()
         if slot is None:
             return None

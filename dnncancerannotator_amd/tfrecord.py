@@ -188,7 +188,7 @@ def parse_example(data):
                     if vnum != 1:
                         continue
                     if knum == 1:                           # BytesList (a serialized tensor stays a view: megabytes of pixels)
-                        values.append(v if len(v) > 4096 else bytes(v))
+                        values.append(v if key == 'slices' and len(v) > 4096 else bytes(v))      # only the pixels stay a view
                     elif knum == 3:                         # Int64List (packed or not)
                         if vwt == 2:
                             pos, raw = 0, bytes(v)
@@ -388,10 +388,22 @@ class TFRecordDataset:
 
     def _exam_lists(self):
         """[exams of file 0], [exams of file 1], ... -- cached files at once, the others through the reader threads"""
-        missing = [p for p in self.paths if p not in self._cache]
-        fresh = read_exams_parallel(missing, self.slice_types, self.workers)
+        # the uncached files are read ahead once each (a path listed twice is read once); results are looked up by PATH, so a
+        # file that entered the cache meanwhile (its second occurrence, another iterator) never shifts the pairing
+        missing = list(dict.fromkeys(p for p in self.paths if p not in self._cache))
+        fresh = zip(missing, read_exams_parallel(missing, self.slice_types, self.workers))
+        got = {}
         for p in self.paths:
-            yield self._exams_of(p) if p in self._cache else self._exams_of(p, next(fresh))
+            if p in self._cache:
+                yield self._exams_of(p)
+                continue
+            while p not in got:
+                q, exams = next(fresh)
+                got[q] = exams
+            exams = self._exams_of(p, got[p])
+            if p in self._cache:
+                del got[p]                       # cached now: a later occurrence comes from there
+            yield exams
 
     def _mine(self, items):
         """this rank's contiguous part of a global batch (a remainder goes to the first ranks: no evaluation sample is dropped)"""

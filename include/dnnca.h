@@ -142,7 +142,9 @@ int dnnca_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
      flip      1 = tf.image.random_flip_left_right took the flip branch (data.py:620-625)
      contrast  factor of tf.image.random_contrast, U[0.8, 1.2) (data.py:586-609); applied to the source channels whose bit is
                set in contrast_mask (never to the label channel); 1.0 = identity
-   Fails with DNNCA_EINVAL when a crop window leaves the source image (tf.image.crop_to_bounding_box asserts the same). */
+   Fails with DNNCA_EINVAL when a crop window leaves the source image (tf.image.crop_to_bounding_box asserts the same).
+   Asynchronous on the model's stream: params_host has been copied when the call returns (it may be reused at once); x_dev / y_dev
+   are complete for later work on that stream (a train step), a host read needs dnnca_sync first. */
 typedef struct { int32_t dy, dx, flip; float contrast; } dnnca_aug_param;
 int dnnca_augment_u8(void* model, const void* src_dev, int batch, int hs, int ws, int cs, int label_index, unsigned contrast_mask,
                      const dnnca_aug_param* params_host, int ho, int wo, float* x_dev, float* y_dev);

@@ -31,6 +31,7 @@ class FakeRing:
 
 class FakeModel:
     max_batch = 4
+    in_shape = (8, 8, 1)
 
     def __init__(self, slot_bytes=1 << 20):
         self.ring = FakeRing(slot_bytes)
@@ -105,6 +106,32 @@ def test_feeder_raw_batches_and_close_while_blocked():
     time.sleep(0.05)                        # the producer now sits on an empty free-slot queue / a full ready queue
     f.close()
     assert not f.thread.is_alive()
+
+
+def test_feeder_never_stages_a_batch_the_built_model_cannot_take():
+    """A float batch of another image size, a uint8 batch cropped to another size / with another channel count / larger than
+    max_batch go to the loop unstaged ('host'): its host path raises DeviceModel._check_x's ValueError or chunks the batch.  Staged,
+    they would reach the kernels as bare pointers -- a 64 x 512 x 512 x 6 uint8 validation batch fills exactly the slot of a
+    256 x 256 model and would be evaluated on misread memory."""
+    dm = FakeModel()
+    ident = lambda a, b=None: (a, b)                             # noqa: E731
+    good, other_size = _batches(1, s=8)[0], _batches(1, s=16)[0]
+    bad_y = (good[0], np.zeros((2, 8, 4), np.float32))
+    raw = np.zeros((2, 12, 12, 2), np.uint8)
+    prm = [(0, 0, 0, 1.0)] * 2
+    elements = [good, other_size, bad_y,
+                augment.RawBatch(raw, prm, (8, 8), 1, None),                                     # fits the built (8, 8, 1) input
+                augment.RawBatch(raw, prm, (6, 6), 1, None),                                     # cropped to another size
+                augment.RawBatch(np.zeros((2, 12, 12, 3), np.uint8), prm, (8, 8), 1, None),      # two feature channels
+                augment.RawBatch(np.zeros((5, 12, 12, 2), np.uint8), [(0, 0, 0, 1.0)] * 5, (8, 8), 1, None)]      # 5 > max_batch
+    f = BatchFeeder(dm, iter(elements), ident)
+    kinds = []
+    for item in f:
+        kinds.append(item[0])
+        if item[0] != 'host':
+            f.release(item[1])
+    f.close()
+    assert kinds == ['staged', 'host', 'host', 'raw', 'host', 'host', 'host']
 
 
 # ---------------------------------------------------------------------------------------------- -m gpu
@@ -208,6 +235,26 @@ def test_engine_train_with_feeder_equals_the_synchronous_loop(gpu, tmp_path, mon
     assert np.allclose(r1.history['val_loss'], r2.history['val_loss'], rtol=2e-4)
     assert list(m1.get_ckpts(str(tmp_path / 'feeder' / 'checkpoints'))) == [4, 8]
     assert m1.current_step == m2.current_step == 11
+
+
+@pytest.mark.gpu
+def test_engine_train_refuses_a_validation_set_of_another_size(gpu, tmp_path):
+    """`annotator train --validate` with data_options whose train and eval sizes differ (data_options.yaml: 256 vs 512): the
+    validation inside train() must raise the shape error, staged or not -- not evaluate misread memory and feed early stopping."""
+    from dnncancerannotator_amd import data, engine
+    config = {'model': 'UNetAnnotator', 'model_options': UNET,
+              'deploy_options': {'optimizer': 'adam', 'loss': {'class_name': 'WeightedCrossentropy', 'config': {'weight_mul': 3.0}},
+                                 'enable_multigpu': False}}
+    ds = data.SyntheticDataset(4, 32, 32, 1, n_batches=3, seed=3)
+    val = data.SyntheticDataset(1, 64, 64, 1, n_batches=1, seed=9, repeat=False)      # same bytes as a 4 x 32 x 32 batch: it "fits" a slot
+    m = engine.TFKerasModel(config)
+    with pytest.raises(ValueError, match='does not match the built input'):
+        m.train(ds, save_path=str(tmp_path / 'run'), max_steps=5, save_freq=2, val_data=val)
+    # device-resident views carry their shapes: the *_dev entry point refuses them as well
+    from dnncancerannotator_amd import device as dev
+    xb, yb = dev.DeviceBuffer(np.zeros((1, 64, 64, 1), np.float32)), dev.DeviceBuffer(np.zeros((1, 64, 64), np.float32))
+    with pytest.raises(ValueError, match='does not match the built input'):
+        m.device_model.train_step_dev(xb, yb, 1, 1e-3, m.device_model.loss_cfg(weight_mul=3.0))
 
 
 @pytest.mark.gpu

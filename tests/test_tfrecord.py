@@ -203,6 +203,29 @@ def test_normalize_exams_interleaves_files_equally(tmp_path):
         T.TFRecordDataset(paths, types, 3, output_size=(32, 32), normalize_exams=True)       # needs the endless training stream
 
 
+def test_a_file_listed_twice_keeps_every_file_with_its_own_exams(tmp_path):
+    """The evaluation stream reads the uncached files ahead on threads and pairs results with paths: a path that occurs twice is
+    read once, and neither its second occurrence nor a cache that fills up mid-pass shifts the pairing (files would otherwise be
+    served -- and cached -- under their neighbour's name).  Also: a long `path` feature still decodes (only `slices` stays a view)."""
+    from dnncancerannotator_amd import tfrecord as T
+    types = ['TRA', 'label']
+    paths = []
+    for i in range(3):
+        s = np.full((2, 40, 40, 2), 10 * (i + 1), np.uint8)
+        p = str(tmp_path / ('exam%d.tfrecords' % i))
+        T.write_records(p, [T.make_example(s, i, i, '/e/' + 'x' * 5000 + '/%d' % i, 'cancer', types)])
+        paths.append(p)
+    order = [paths[0], paths[1], paths[0], paths[2]]
+    want = [10, 10, 20, 20, 10, 10, 30, 30]
+    for cache_bytes in (8 << 30, 2 * 40 * 40 * 2 + 1, 0):           # everything cached / room for one file / no cache
+        ds = T.TFRecordDataset(order, types, 2, output_size=(32, 32), device_convert=True, workers=3, cache_bytes=cache_bytes)
+        for _ in range(2):                                          # second pass: from the cache where there is one
+            assert [int(el.raw[k, 5, 5, 0]) for el in ds for k in range(len(el.raw))] == want
+        for q, exams in ds._cache.items():
+            assert int(exams[0].slices[0, 5, 5, 0]) == 10 * (paths.index(q) + 1)
+    assert next(iter(T.read_exams(paths[1]))).path.endswith('/1')
+
+
 def test_dataset_level_sharding_for_data_parallel(tmp_path):
     """shard=(rank, world): every rank walks the same slice stream and makes the same draws but assembles only its contiguous part
     of each global batch (engine._shard's split, before stacking / solving / uploading); evaluation remainders go to the first ranks"""
