@@ -15,6 +15,21 @@ BIG_CASES = ['mulmo_yaml_2x64', 'unet_big_f8_2x64']
 
 PARAM_SEED = 2
 
+# ---- which kernels have met the oracle?  Every -m gpu test that compares a train step with the float64 / bf16-emulating oracle
+# (or with a golden fixture made by it) registers the launch names of the model it checked; tests/test_zz_kernel_coverage.py
+# closes the loop: every launch of the three BASELINE configurations at full size must be in this set.
+ORACLE_KERNELS = set()
+ORACLE_TESTS = set()
+
+
+def record_oracle_plan(model_or_names, test):
+    """`model_or_names`: a DeviceModel (its plan() -- the launch schedule of one train step under the current switches) or an
+    iterable of launch names (a child process's); `test`: the registering test function's name."""
+    names = model_or_names if isinstance(model_or_names, (list, tuple, set)) else [r[0] for r in model_or_names.plan()]
+    ORACLE_KERNELS.update(names)
+    ORACLE_TESTS.add(test)
+
+
 
 def perturbed_params(spec, dtype):
     """glorot kernels (seed 2) + small non-zero biases / BN parameters so every term is exercised."""

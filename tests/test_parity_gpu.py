@@ -75,6 +75,8 @@ def _run_case(gpu, name, force_generic):
         assert np.abs(pa - paref).max() <= 2.0 * lr + 1e-7   # the rest: never farther than a full step each way
         if m.n_state:
             assert np.abs(m.get_state() - z['state_after']).max() <= 1e-5
+        if not force_generic:
+            Hp.record_oracle_plan(m, 'test_golden_tuned_kernels')
     finally:
         m.close()
 
