@@ -12,7 +12,8 @@
 //   conv's sources with a halo of 1; DOWN: dz1 = (skip gradient + pooled gradient at the recorded window position) * act'(y1)
 //   P1   dz0 = dgrad_conv1(dz1) * act'(y0) on the tile enlarged by one pixel -> LDS     |  dW1 += y0 (x) dz1
 //   P2   dgrad_conv0(dz0) on the tile: UP [d_up -> LDS | d_skip -> HBM], DOWN dx -> HBM |  dW0 += sources (x) dz0
-//   P3   UP: the transposed conv's data gradient from d_up -> HBM                       |  its weight + bias gradient
+//        then, wave-locally (every data-gradient wave owns a rectangle of the tile):
+//        UP: the transposed conv's data gradient, weight + bias gradient from d_up
 // The block's eight waves SPLIT: waves [0, 4) run the data-gradient convolutions (left column: B operands in registers, no
 // accumulator outlives a phase), waves [4, 8) the weight gradients (right column: every accumulator lives in registers across the
 // whole persistent tile loop).  Every SIMD hosts one wave of each kind, so the matrix pipe always has two independent MFMA
@@ -43,13 +44,15 @@ struct DConv3 {
     static constexpr int G = 12 / CO, GC = G * C, WR = (G + 2) * C, SR = (WR + 3) / 4, KS = 3 * SR, ILS = RG * GC;
     static constexpr int NMT = MPR ? OROWS * MPR : cdiv(OROWS * RG, 16), CH = cdiv(NMT, NW);
     static_assert(MPR == 0 || (NW % MPR == 0 && NMT % NW == 0), "row-aligned M-tiles must divide evenly over the waves");
-    static constexpr int CSTEP = MPR ? (NW / MPR) * RG * GC : NW * 16 * GC;
+    // MPR > 0: wave w owns column block w % MPR of the CH consecutive rows (w / MPR) * CH ..: a rectangle of 16 groups x CH rows of
+    // the output, which the caller may go on working with right away (same wave: DS operations execute in order)
+    static constexpr int CSTEP = MPR ? RG * GC : NW * 16 * GC;
 
     static __device__ __forceinline__ void run(const float* in, float* out, const float* breg, const float* msk, float malpha, int wave, int lane) {
         const int m = lane & 15, q = lane >> 4, n = m;
         constexpr bool RAGGED = CH * NW > NMT;
         const bool last_ok = !RAGGED || wave + (CH - 1) * NW < NMT;           // wave-uniform
-        const int g0 = MPR ? (wave / MPR) * RG + (wave % MPR) * 16 : wave * 16;
+        const int g0 = MPR ? (wave / MPR) * CH * RG + (wave % MPR) * 16 : wave * 16;
         const float* a0 = in + ILEAD + q + (g0 + m) * GC;
         const float* al = RAGGED ? in + ILEAD + q + ((last_ok ? wave + (CH - 1) * NW : NMT - 1) * 16 + m) * GC : a0 + (CH - 1) * CSTEP;
         f32x4 acc[CH];
@@ -73,15 +76,17 @@ struct DConv3 {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (n < 12) {
-            const int o0 = OLEAD + (wave * 16 + 4 * q) * 12 + n;
+            // M-tile index of chain c: linear (wave + c NW), or row-aligned ((w / MPR) CH + c) MPR + w % MPR
+            const int o0 = OLEAD + ((MPR ? (wave / MPR) * CH * MPR + wave % MPR : wave) * 16 + 4 * q) * 12 + n;
+            constexpr int OSTEP = (MPR ? MPR : NW) * 192;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if (c < CH - 1 || last_ok) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[c][r];
-                        if (msk) v *= msk[o0 + c * (NW * 192) + r * 12] > 0.f ? 1.0f : malpha;
-                        out[o0 + c * (NW * 192) + r * 12] = v;
+                        if (msk) v *= msk[o0 + c * OSTEP + r * 12] > 0.f ? 1.0f : malpha;
+                        out[o0 + c * OSTEP + r * 12] = v;
                     }
                 }
             }
@@ -195,7 +200,7 @@ struct BArgs {
 
 // UP:   CA == F; NSRC = 2; the first conv's data gradient has 2F channels = NPASS passes of 12 ([up | skip])
 // DOWN: CA = the block's input channels; NSRC = 1
-template <bool UP, int CA, int F, int TW, int NT, int ISSUE_DG = 2, int ISSUE_WG = 3>
+template <bool UP, int CA, int F, int TW, int NT, int ISSUE_DG = 2, int ISSUE_WG = 2>
 __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
     constexpr int TH = 8, NW = NT / 64, NWD = NW / 2, NWW = NW - NWD, NSRC = UP ? 2 : 1, CT = 12;
     constexpr int KID = (UP ? 0 : 2) + (F == 12 ? 1 : 0);      // tuning builds: which stamp table
@@ -232,8 +237,12 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
     constexpr int O_OUT = O_DZ1;                                                  // stage-2 output tiles alias dz1 (dead after P1)
     static_assert(NPASS * OUT2 <= TDZ1::N, "stage-2 output tiles must fit the dz1 tile");
     constexpr int MT1 = W1::MT, MT0 = W0::MT;
-    constexpr int ACCF = (MT1 + NSRC * MT0 + (UP ? MBt : 0)) * 256;               // floats of one weight-gradient wave's sums
-    static_assert(NWW * ACCF <= LDSN, "the final reduction must fit the LDS");
+    constexpr int ACCF = (MT1 + NSRC * MT0) * 256;                                // floats of one weight-gradient wave's sums
+    constexpr int TACCF = UP ? MBt * 256 : 0;                                     // ... of one data-gradient wave's (transposed conv)
+    static_assert(NWW * ACCF + NWD * TACCF <= LDSN, "the final reduction must fit the LDS");
+    // a data-gradient wave's rectangle of the stage-2 output: RPW rows x 16 groups, i.e. (UP) 8 x RPW/2 transposed-conv input pixels
+    constexpr int RPW = TH / (NWD / MPR2), LPW = 8 * (RPW / 2);
+    static_assert(NWD % MPR2 == 0 && TH % (NWD / MPR2) == 0 && (!UP || (RPW % 2 == 0 && LPW % 16 == 0)), "wave rectangles");
     static_assert(LDSN * 4 <= 160 * 1024, "LDS budget");
     __shared__ float4 lds4[(LDSN + 3) / 4];
     float* lds = reinterpret_cast<float*>(lds4);
@@ -395,6 +404,10 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
         f32x4 acc1[1][MT1], acc0[NSRC][MT0], tacc[UP ? MBt : 1];
         W1 w1;
         W0 w0;
+        if constexpr (DG) {
+#pragma unroll
+            for (int t = 0; t < (UP ? MBt : 1); ++t) tacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if constexpr (!DG) {
 #pragma unroll
             for (int t = 0; t < MT1; ++t) acc1[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -402,8 +415,6 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
             for (int s = 0; s < NSRC; ++s)
 #pragma unroll
                 for (int t = 0; t < MT0; ++t) acc0[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < (UP ? MBt : 1); ++t) tacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             w1.init(lane, TY0::LEAD, TY0::LS, CST1, CST0);
             w0.init(lane, TXA::LEAD, TXA::LS, CST1, CST0);
         }
@@ -453,44 +464,36 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
                     load_breg<DC0::KS>(breg, lds + O_BM0 + ps * DC0::KS * 64, lane);
                     DC0::run(lds + O_DZ0, lds + O_OUT + ps * OUT2, breg, nullptr, 0.f, wv, lane);
                 }
-            } else {
-#pragma unroll 1
-                for (int ty = wv; ty < TH; ty += NWW) {
-                    int xr[NSRC];
+                // ---- the wave's rectangle of the tile leaves (and, UP, feeds the transposed conv's backward): rows [r0, r0 + RPW) x
+                // column block cbk of 16 groups -- written by this wave just now, so no workgroup barrier is needed
+                __builtin_amdgcn_wave_barrier();
+                const int r0 = (wv / MPR2) * RPW, cbk = wv % MPR2;
+                if constexpr (UP) {
+                    // skip gradient: channels [F, 2F) of the first conv's data gradient, 16 pixels per row
+                    float* base = p.dxb + ((size_t)cb * p.H + cy0 + r0) * p.W * F + (size_t)(cx0 + cbk * 16) * F;
+                    if constexpr (NPASS == 2) {           // pass 1 is the skip half: 16 x F floats = 48 float4 per row
+                        static_assert(F == 12, "two passes: 12 channels per pass");
+                        if (lane < 48) {
 #pragma unroll
-                    for (int s = 0; s < NSRC; ++s) xr[s] = O_XA + s * TXA::N + ty * TXA::LS;
-                    w0.template row<NSRC>(acc0, ldsf, xr, O_DZ0 + TY0::LEAD + (ty + 1) * TY0::LS + F, CST0, lane);
-                }
-            }
-            FZB_STAMP(!DG, it < 3 ? 6 + 8 * it : 99);
-            lds_barrier();
-            FZB_STAMP(!DG, it < 3 ? 7 + 8 * it : 99);
-            // ---- P3: the tile's gradients leave
-            if constexpr (ISSUE_AT == 3) prefetch();
-            if constexpr (UP) {
-                // skip gradient: channels [F, 2F) of the first conv's data gradient
-                float* base = p.dxb + ((size_t)cb * p.H + cy0) * p.W * F + (size_t)cx0 * F;
-                if constexpr (NPASS == 2) {           // pass 1 is the skip half: dense rows of TW * F floats
-                    constexpr int R4 = TW * F / 4;
-                    for (int idx = tid; idx < TH * R4; idx += NT) {
-                        const int r = idx / R4, c4 = idx - r * R4;
-                        *reinterpret_cast<float4*>(base + (size_t)r * p.W * F + 4 * c4) = reinterpret_cast<const float4*>(lds + O_OUT + OUT2)[idx];
+                            for (int rr = 0; rr < RPW; ++rr)
+                                *reinterpret_cast<float4*>(base + (size_t)rr * p.W * F + 4 * lane) =
+                                    *reinterpret_cast<const float4*>(lds + O_OUT + OUT2 + (r0 + rr) * ROWF + cbk * 192 + 4 * lane);
+                        }
+                    } else {                              // one pass: 12 floats per pixel = [up (F) | skip (F)]; 16 x F floats = 48 float2 per row
+                        static_assert(F == 6, "one pass: [up | skip] of 6 channels each");
+                        if (lane < 48) {
+                            const int px = (2 * lane) / F, ch = 2 * lane - px * F;
+#pragma unroll
+                            for (int rr = 0; rr < RPW; ++rr)
+                                *reinterpret_cast<float2*>(base + (size_t)rr * p.W * F + 2 * lane) =
+                                    *reinterpret_cast<const float2*>(lds + O_OUT + (r0 + rr) * ROWF + (cbk * 16 + px) * 12 + F + ch);
+                        }
                     }
-                } else {                              // one pass: 12 floats per pixel = [up (F) | skip (F)]
-                    constexpr int R2 = TW * F / 2;
-                    static_assert(F % 2 == 0, "float2 pieces of the interleaved tile");
-                    for (int idx = tid; idx < TH * R2; idx += NT) {
-                        const int r = idx / R2, j = idx - r * R2;
-                        const int px = (2 * j) / F, ch = 2 * j - px * F;
-                        *reinterpret_cast<float2*>(base + (size_t)r * p.W * F + 2 * j) =
-                            *reinterpret_cast<const float2*>(lds + O_OUT + r * ROWF + px * 12 + F + ch);
-                    }
-                }
-                // LDS addressing of the transposed conv's GEMMs; the gradient of its output is the `up` half of the stage-2 tile:
-                // pixel (r, c) channel co at O_OUT + r * ROWF + c * 12 + co
-                const int m16 = lane & 15, q = lane >> 4;
-                if constexpr (DG) {
-                    // T1: din[i][j][ci] = sum_(a,e,co) dup[2i+a][2j+e][co] W[a][e][co][ci];  M = 16 input pixels of a row, N = ci
+                    // the transposed conv's backward on the wave's 8 x RPW/2 input pixels; the gradient of its output is the `up` half of the
+                    // stage-2 tile: pixel (r, c) channel co at O_OUT + r * ROWF + c * 12 + co
+                    const int m16 = lane & 15, q = lane >> 4;
+                    const int lr0 = r0 / 2, lc0 = cbk * 8;                  // the rectangle's first input pixel (tile coordinates)
+                    // T1: din[i][j][ci] = sum_(a,e,co) dup[2i+a][2j+e][co] W[a][e][co][ci];  M = 16 input pixels (8 wide, 2 rows), N = ci
                     int koff[KS1t];
 #pragma unroll
                     for (int kk = 0; kk < KS1t; ++kk) {
@@ -499,16 +502,15 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
                     }
                     const int woff = m16 < CT ? O_TCW + q * CT + m16 : CST0, wstep = m16 < CT ? 4 * CT : 0;
                     float* orow = lds + O_ROW + wv * 192;
-#pragma unroll 1
-                    for (int mt = wv; mt < NLP / 16; mt += NWD) {
-                        const int li = mt / (LWt / 16), mx = mt - li * (LWt / 16);
-                        // operands first (all LDS reads in flight), then one MFMA chain per output-row parity
+#pragma unroll
+                    for (int mt = 0; mt < LPW / 16; ++mt) {
+                        const int li = lr0 + 2 * mt + (m16 >> 3), lj = lc0 + (m16 & 7);
                         float ta[2][KS1t], tb[2][KS1t];
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
 #pragma unroll
                             for (int kk = 0; kk < KS1t; ++kk) {
-                                ta[a][kk] = ldsf[O_OUT + (2 * li + a) * ROWF + 2 * (mx * 16 + m16) * 12 + koff[kk]];
+                                ta[a][kk] = ldsf[O_OUT + (2 * li + a) * ROWF + 2 * lj * 12 + koff[kk]];
                                 tb[a][kk] = ldsf[woff + (a * KS1t + kk) * wstep];
                             }
                         __builtin_amdgcn_sched_barrier(0);
@@ -520,42 +522,41 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
                         const f32x4 d = d2[0] + d2[1];
                         if (m16 < CT) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) orow[(4 * q + r) * CT + m16] = d[r];
+                            for (int r = 0; r < 4; ++r) orow[(4 * q + r) * CT + m16] = d[r];      // row = input pixel 4q + r of the M-tile
                         }
                         __builtin_amdgcn_wave_barrier();
                         if (lane < 16 * CT / 4) {
+                            const int px = lane / 3, c4 = lane - 3 * px;                     // input pixel (px >> 3, px & 7) of the M-tile
+                            const int oi = lr0 + 2 * mt + (px >> 3), oj = lc0 + (px & 7);
                             float4 v = reinterpret_cast<const float4*>(orow)[lane];
                             if (p.tc_mask) {
-                                const float4 xv = reinterpret_cast<const float4*>(lds + O_LOW)[(li * LWt + mx * 16) * 3 + lane];
+                                const float4 xv = reinterpret_cast<const float4*>(lds + O_LOW)[(oi * LWt + oj) * 3 + c4];
                                 v.x *= xv.x > 0.f ? 1.0f : p.tc_alpha;
                                 v.y *= xv.y > 0.f ? 1.0f : p.tc_alpha;
                                 v.z *= xv.z > 0.f ? 1.0f : p.tc_alpha;
                                 v.w *= xv.w > 0.f ? 1.0f : p.tc_alpha;
                             }
-                            reinterpret_cast<float4*>(p.tc_din)[(((size_t)cb * (p.H >> 1) + (cy0 >> 1) + li) * (p.W >> 1) + (cx0 >> 1) + mx * 16) * 3 + lane] = v;
+                            reinterpret_cast<float4*>(p.tc_din)[(((size_t)cb * (p.H >> 1) + (cy0 >> 1) + oi) * (p.W >> 1) + (cx0 >> 1) + oj) * 3 + c4] = v;
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
-                } else {
                     // T2: dW[(a,e,co)][ci] += sum_pixels dup[..](a,e,co) * in[i][j][ci];  M = (a, e, co), N = ci (+ an all-ones column: the
-                    // bias gradient), K = the tile's input pixels, four per step, dealt to the weight-gradient waves
+                    // bias gradient), K = the rectangle's input pixels, four of one row per step
                     int offT[MBt];
                     bool valT[MBt];
 #pragma unroll
                     for (int t = 0; t < MBt; ++t) {
                         const int k = 16 * t + m16, a = k / KA, kr = k - a * KA, e = kr / F;
                         valT[t] = k < KTt;
-                        offT[t] = valT[t] ? O_OUT + a * ROWF + 2 * q * 12 + e * 12 + (kr - e * F) : CST0;
+                        offT[t] = valT[t] ? O_OUT + a * ROWF + e * 12 + (kr - e * F) : CST0;
                     }
-                    const int boff = m16 < CT ? O_LOW + q * CT + m16 : (m16 == CT ? CST1 : CST0), bstep = m16 < CT ? 4 * CT : 0;
-                    constexpr int KST = NLP / 4 / NWW;
-                    static_assert(NLP / 4 % NWW == 0, "T2: K-steps divide evenly over the weight-gradient waves");
+                    constexpr int KST = LPW / 4;
                     float tbv[KST], tav[KST][MBt];
 #pragma unroll
                     for (int i = 0; i < KST; ++i) {
-                        const int st = wv + i * NWW;
-                        const int sd = ((4 * st) / LWt) * 2 * ROWF + ((4 * st) % LWt) * 2 * 12;
-                        tbv[i] = ldsf[boff + st * bstep];
+                        const int li = lr0 + i / 2, lj = lc0 + (i & 1) * 4 + q;          // this lane's input pixel of K-step i
+                        tbv[i] = m16 < CT ? ldsf[O_LOW + (li * LWt + lj) * CT + m16] : (m16 == CT ? 1.0f : 0.0f);
+                        const int sd = 2 * li * ROWF + 2 * lj * 12;
 #pragma unroll
                         for (int t = 0; t < MBt; ++t) tav[i][t] = ldsf[offT[t] + (valT[t] ? sd : 0)];
                     }
@@ -564,9 +565,25 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
                     for (int i = 0; i < KST; ++i)
 #pragma unroll
                         for (int t = 0; t < MBt; ++t) tacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tav[i][t], tbv[i], tacc[t], 0, 0, 0);
+                } else {
+                    // gradient of the block's input: the wave's RPW full-width rows of TW * CA floats (= 48 float4)
+                    static_assert(MPR2 == 1 && TW * CA == 192, "DOWN: a wave stores whole rows of 48 float4");
+                    float* base = p.dxb + ((size_t)cb * p.H + cy0 + r0) * p.W * CA + (size_t)cx0 * CA;
+                    if (lane < 48) {
+#pragma unroll
+                        for (int rr = 0; rr < RPW; ++rr)
+                            *reinterpret_cast<float4*>(base + (size_t)rr * p.W * CA + 4 * lane) =
+                                *reinterpret_cast<const float4*>(lds + O_OUT + (r0 + rr) * (TW * CA) + 4 * lane);
+                    }
                 }
             } else {
-                store_interior<CA, G2, TW / G2, TH, 0, TW, TH, NT>(lds + O_OUT, p.dxb, cb, cy0, cx0, p.H, p.W, tid);
+#pragma unroll 1
+                for (int ty = wv; ty < TH; ty += NWW) {
+                    int xr[NSRC];
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s) xr[s] = O_XA + s * TXA::N + ty * TXA::LS;
+                    w0.template row<NSRC>(acc0, ldsf, xr, O_DZ0 + TY0::LEAD + (ty + 1) * TY0::LS + F, CST0, lane);
+                }
             }
             FZB_STAMP(!DG, it < 3 ? 8 + 8 * it : 99);
             const bool more = tile < ntiles;                  // the registers hold a tile
@@ -596,12 +613,12 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
                 for (int t = 0; t < MT0; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[(MT1 + s * MT0 + t) * 256 + r * 64 + lane] = acc0[s][t][r];
-            if constexpr (UP) {
+        } else if constexpr (UP) {
+            float* red = lds + NWW * ACCF + wv * TACCF;           // the transposed conv's sums: behind the weight-gradient waves' areas
 #pragma unroll
-                for (int t = 0; t < MBt; ++t)
+            for (int t = 0; t < MBt; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[(MT1 + NSRC * MT0 + t) * 256 + r * 64 + lane] = tacc[t][r];
-            }
+                for (int r = 0; r < 4; ++r) red[t * 256 + r * 64 + lane] = tacc[t][r];
         }
     };
     if (wave < NWD) role(std::true_type{});
@@ -614,22 +631,21 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
     if (p.dbg & 1) return;
 #endif
     const int bucket = blockIdx.x % kPgBuckets;
-    auto flush = [&](int first, int mt, float* slab, int rows, int cols) {
+    // first: float offset of the D inside a wave's area; nw waves, `stride` floats apart, hold partial sums of it
+    auto flush = [&](int first, int nw, int stride, int mt, float* slab, int rows, int cols) {
         for (int i = tid; i < mt * 256; i += NT) {
             const int t = i >> 8, r = (i >> 6) & 3, ln = i & 63;
             if ((ln & 15) < cols && 16 * t + 4 * (ln >> 4) + r < rows) {
-                const int o = first * 256 + i;
                 float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < NWW; ++w) v += lds[w * ACCF + o];
+                for (int w = 0; w < nw; ++w) v += lds[first + w * stride + i];
                 atomicAdd(slab + (size_t)bucket * (mt * 256) + i, v);
             }
         }
     };
-    flush(0, MT1, p.slabs1, W1::MROWS, 12);
+    flush(0, NWW, ACCF, MT1, p.slabs1, W1::MROWS, 12);
 #pragma unroll
-    for (int s = 0; s < NSRC; ++s) flush(MT1 + s * MT0, MT0, p.slabs0[s], W0::MROWS, 12);
-    if constexpr (UP) flush(MT1 + NSRC * MT0, MBt, p.tc_slabs, KTt, CT + 1);
+    for (int s = 0; s < NSRC; ++s) flush((MT1 + s * MT0) * 256, NWW, ACCF, MT0, p.slabs0[s], W0::MROWS, 12);
+    if constexpr (UP) flush(NWW * ACCF, NWD, TACCF, MBt, p.tc_slabs, KTt, CT + 1);
     FZB_STAMP(wave >= NWD, 31);
 }
 

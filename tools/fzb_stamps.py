@@ -42,8 +42,8 @@ for kid, kname in enumerate(('up1', 'up2', 'down1', 'down2')):
           if not (r[:, base] > 0).all():
               break
           prev = r[:, 2] if it == 0 else r[:, base - 1]
-          d = [np.median(r[:, base + k] - r[:, base + k - 1]) for k in range(1, 6)]
-          line.append('| tile%d gap %d P1 %d bar %d P2 %d bar %d P3 %d' % (it, np.median(r[:, base] - prev), *d))
+          line.append('| tile%d gap %d P1 %d bar %d P2+epilogue %d' % (it, np.median(r[:, base] - prev), np.median(r[:, base + 1] - r[:, base]),
+                      np.median(r[:, base + 2] - r[:, base + 1]), np.median(r[:, base + 5] - r[:, base + 2])))
           if (r[:, base + 7] > 0).all():
               line.append('bar %d commit %d' % (np.median(r[:, base + 6] - r[:, base + 5]), np.median(r[:, base + 7] - r[:, base + 6])))
       if (r[:, 25] > 0).all():
