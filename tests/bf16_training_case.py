@@ -52,7 +52,7 @@ def train(device, dtype, steps, env=()):
     curve, last = [], []
     for step in range(steps):
         x, y = train_set[step % len(train_set)]
-        lr = 1e-3 * 0.96 ** (step // 100)
+        lr = 1e-3 if step < 2 * steps // 3 else 1e-4          # the last third anneals: the runs settle instead of bouncing
         out = m.train_step(x, y, lr, cfg)
         if step % 10 == 0 or step == steps - 1:
             curve.append(round(float(out.loss), 5))
