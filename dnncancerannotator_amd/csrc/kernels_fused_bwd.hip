@@ -435,7 +435,8 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
             };
             constexpr int ISSUE_AT = DG ? ISSUE_DG : ISSUE_WG;
             if constexpr (ISSUE_AT == 1) prefetch();
-            // ---- P1
+            // ---- P1 (the data-gradient waves are this phase's long pole: they go first on the SIMD both kinds share)
+            __builtin_amdgcn_s_setprio(DG ? 2 : 0);
             if constexpr (DG) {
                 float breg[DC1::KS];
                 load_breg<DC1::KS>(breg, lds + O_BM1, lane);
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(NT, 1) void k_fzb(BArgs p) {
                 lds_barrier();
             }
             // ---- P2
+            __builtin_amdgcn_s_setprio(0);           // (the other way round in P2 only swapped the two roles' finishing order)
             if constexpr (ISSUE_AT == 2) prefetch();
             if constexpr (DG) {
 #pragma unroll

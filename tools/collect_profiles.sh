@@ -23,9 +23,9 @@ pass() {   # pass <name> <rocprofv3 options...> -- <program...>
 }
 
 if [ "$WHAT" = unet ] || [ "$WHAT" = all ]; then
-    pass unet_stats --kernel-trace --stats -d "$OUT/raw_unet_stats" -f csv -- python3 "$R/bench.py" --steps 100 --warmup 20 --no-cpu-baseline || exit 1
-    pass unet_fetch --pmc FETCH_SIZE -d "$OUT/raw_unet_fetch" -f csv -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline || exit 1
-    pass unet_write --pmc WRITE_SIZE -d "$OUT/raw_unet_write" -f csv -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline || exit 1
+    pass unet_stats --kernel-trace --stats -d "$OUT/raw_unet_stats" -f csv -- python3 "$R/bench.py" --steps 100 --warmup 20 --no-cpu-baseline --no-other-workloads || exit 1
+    pass unet_fetch --pmc FETCH_SIZE -d "$OUT/raw_unet_fetch" -f csv -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-other-workloads || exit 1
+    pass unet_write --pmc WRITE_SIZE -d "$OUT/raw_unet_write" -f csv -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-other-workloads || exit 1
 fi
 if [ "$WHAT" = dense ] || [ "$WHAT" = all ]; then
     for wl in unet_big mulmo_unet; do
