@@ -36,6 +36,9 @@ def short_name(k):
         extra = [t.strip() for t in m.group(4).split(',') if t.strip()]     # TW, TH, NT, MINW[, NF]
         ride = 'tc_' if m.group(1) == 'up' and len(extra) >= 5 and extra[4] != '0' else ''
         return 'fz_%s_%s%s_%s' % (m.group(1), ride, m.group(2), m.group(3))
+    m = re.match(r'dnnca::fzb::k_fzb<(true|false), (\d+), (\d+)', k)
+    if m:
+        return 'fzb_up_%s' % m.group(3) if m.group(1) == 'true' else 'fzb_down_%s_%s' % (m.group(2), m.group(3))
     m = re.match(r'dnnca::k_bwd3v<(true|false)', k)
     if m:
         return 'bwd3v_pool_3x1_3' if m.group(1) == 'true' else 'bwd3v_3x1_3'
