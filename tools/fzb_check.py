@@ -45,7 +45,7 @@ def per_tensor(g, gref):
     return sorted(worst, reverse=True)
 
 
-shapes = [(2, 64, 256), (3, 32, 128)] + ([(8, 512, 512)] if '--full' in sys.argv else [])
+shapes = [(2, 64, 256), (3, 32, 128)] + ([(8, 512, 512), (16, 512, 512), (5, 256, 384)] if '--full' in sys.argv else [])
 for leaky in (0.0, 0.3):
     for B, H, W in shapes:
         l0, g0, plan0 = run(B, H, W, {'DNNCA_NO_FUSED_BWD': '1'}, leaky)
