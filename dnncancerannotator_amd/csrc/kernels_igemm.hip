@@ -2407,6 +2407,7 @@ static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* nam
             a2.tiles_y = (a.H + 4 * nw - 1) / (4 * nw);
             const unsigned units = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / (16 * nn3)));
             const unsigned g = units < 256u ? units : 256u;
+            m->set_variant("3n%dw%d", nn3, nn3 == 4 ? 4 : nw);
             if (nn3 == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<4, MODE, 4>), dim3(g), dim3(256), 0, m->stream, a2));
             else if (nn3 == 2 && nw == 8) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<2, MODE, 8>), dim3(g), dim3(512), 0, m->stream, a2));
             else if (nn3 == 2) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv3<2, MODE, 4>), dim3(g), dim3(256), 0, m->stream, a2));
@@ -2417,6 +2418,7 @@ static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* nam
     }
     const int nn = pick_nn(cout);
     dim3 grid(a.tiles_x * a.tiles_y * a.B, cout / (16 * nn));
+    m->set_variant("n%d", nn);
     if (nn == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv<4, MODE>), grid, dim3(256), 0, m->stream, a));
     else if (nn == 2) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv<2, MODE>), grid, dim3(256), 0, m->stream, a));
     else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig::k_ig_conv<1, MODE>), grid, dim3(256), 0, m->stream, a));
@@ -2444,6 +2446,7 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
         return;
     }
     dim3 grid(a.tiles_x * a.tiles_y * a.B, cout / (16 * nn));
+    m->set_variant("n%d", nn);
     if (nn == 4) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv<4, MODE>), grid, dim3(256), 0, m->stream, a, w16));
     else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv<2, MODE>), grid, dim3(256), 0, m->stream, a, w16));
 }
@@ -2543,10 +2546,12 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
                 const bool xh = (s == 0 ? o.inA.d.h : o.inB.d.h) != 0, gh = o.out.g.h != 0;
                 static const int narrow = getenv("DNNCA_WGRAD64_NARROW") != nullptr;          // tuning aid
                 if (xh && gh && !narrow && (double)B * w.H * w.W * (w.cs > CO ? w.cs : CO) * 2.0 < 2.0e9) {         // eight waves per block (bf16-stored operands, 32-bit byte offsets)
+                    m->set_variant("w8");
                     LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL(igb::k_igb_wgrad64w, g64, dim3(512), 0, m->stream, w));
                     continue;
                 }
     #define WG64(XH, GH) LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad64<XH, GH>), g64, dim3(256), 0, m->stream, w))
+                m->set_variant("x%dg%d", (int)xh, (int)gh);
                 if (xh) { if (gh) WG64(true, true); else WG64(true, false); }
                 else { if (gh) WG64(false, true); else WG64(false, false); }
     #undef WG64
@@ -2565,10 +2570,11 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
     #define WG2N(MWv) do { if (nn == 4) WG2(MWv, 4, 4); \
                            else if (nn == 2) { if (wg2_narrow) WG2(MWv, 2, 4); else WG2(MWv, 2, 8); } \
                            else { if (wg2_narrow) WG2(MWv, 1, 4); else WG2(MWv, 1, 8); } } while (0)
+                m->set_variant("m%dn%dw%d", mw, nn, nn == 4 || wg2_narrow ? 4 : 8);
                 if (mw == 4) WG2N(4); else if (mw == 2) WG2N(2); else WG2N(1);
     #undef WG2N
     #undef WG2
-            } else if (use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
+            } else if (m->set_variant("n%d", nn), use_bf16(m, o) && nn == 4) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<4>), grid, dim3(256), 0, m->stream, w));
             else if (use_bf16(m, o) && nn == 2) LAUNCH(m, "igb_wgrad", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad<2>), grid, dim3(256), 0, m->stream, w));
             else if (nn == 4) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<4>), grid, dim3(256), 0, m->stream, w));
             else if (nn == 2) LAUNCH(m, "ig_wgrad", bb, ff, hipLaunchKernelGGL((ig::k_ig_wgrad<2>), grid, dim3(256), 0, m->stream, w));
@@ -2652,6 +2658,7 @@ bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_nex
             }
         }
         const dim3 grid((a.npix + 127) / 128, a.cout / 64);
+        m->set_variant("h%d", (int)(o.inA.d.h != 0));
         if (o.inA.d.h)
             LAUNCH(m, "igb_tconv_fwd", bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_fwd<true>, grid, dim3(256), 0, m->stream, a, pl.wf + o.w_off));
         else
@@ -2660,6 +2667,7 @@ bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_nex
     }
     const int nn = pick_nn(a.cout);
     dim3 grid((a.npix + 127) / 128, a.cout / (16 * nn), 4);
+    m->set_variant("n%d", nn);
     if (nn == 4) LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd<4>), grid, dim3(256), 0, m->stream, a));
     else if (nn == 2) LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd<2>), grid, dim3(256), 0, m->stream, a));
     else LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd<1>), grid, dim3(256), 0, m->stream, a));
@@ -2680,10 +2688,12 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
 #define TW64(XH, GH) LAUNCH(m, "igb_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((igb::k_igb_tconv_wgrad64<XH, GH>), gw, dim3(256), 0, m->stream, a))
         hipStream_t main_stream = m->stream;
         const bool side = m->wg_side_begin();          // a leaf of the backward pass: on the side stream where the step allows
+        m->set_variant("x%dg%d", (int)xh, (int)gh);
         if (xh) { if (gh) TW64(true, true); else TW64(true, false); }
         else { if (gh) TW64(false, true); else TW64(false, false); }
         if (side) m->wg_side_end(main_stream);
 #undef TW64
+        m->set_variant("g%d", (int)gh);
         if (gh)
             LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_dgrad<true>, gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
         else
@@ -2703,6 +2713,7 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
         a.psplit = ps < 1 ? 1 : ps;
         dim3 g2(a.psplit, a.cout / (16 * mw), a.cin / (16 * nn));
 #define TW2(MWv, NNv) LAUNCH(m, "ig_tconv_wgrad2", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad2<MWv, NNv>), g2, dim3(256), 0, m->stream, a))
+        m->set_variant("m%dn%d", mw, nn);
         if (mw == 4) { if (nn == 4) TW2(4, 4); else if (nn == 2) TW2(4, 2); else TW2(4, 1); }
         else if (mw == 2) { if (nn == 4) TW2(2, 4); else if (nn == 2) TW2(2, 2); else TW2(2, 1); }
         else { if (nn == 4) TW2(1, 4); else if (nn == 2) TW2(1, 2); else TW2(1, 1); }
@@ -2715,6 +2726,7 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
         if (psplit > ntiles) psplit = ntiles;
         a.psplit = psplit < 1 ? 1 : psplit;
         dim3 grid(a.psplit, a.cout / 16, 4 * (a.cin / (16 * nn)));
+        m->set_variant("n%d", nn);
         if (nn == 4) LAUNCH(m, "ig_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad<4>), grid, dim3(256), 0, m->stream, a));
         else if (nn == 2) LAUNCH(m, "ig_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad<2>), grid, dim3(256), 0, m->stream, a));
         else LAUNCH(m, "ig_tconv_wgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_wgrad<1>), grid, dim3(256), 0, m->stream, a));
@@ -2723,6 +2735,7 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
     {
         const int nn = pick_nn(a.cin);
         dim3 grid((a.npix + 127) / 128, a.cin / (16 * nn));
+        m->set_variant("n%d", nn);
         if (nn == 4) LAUNCH(m, "ig_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_dgrad<4>), grid, dim3(256), 0, m->stream, a));
         else if (nn == 2) LAUNCH(m, "ig_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_dgrad<2>), grid, dim3(256), 0, m->stream, a));
         else LAUNCH(m, "ig_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_dgrad<1>), grid, dim3(256), 0, m->stream, a));

@@ -174,6 +174,10 @@ struct Model {
     bool merged_launches() const { return prof_mode != 3; }
     bool dry = false;
     std::string focus, plan_text;
+    // the template variant of the next launch ("n4w8", "m2n4w4", ...): appended to the launch name as `name#variant` in the dry
+    // plan only (dnnca_plan_dump) -- the kernel-coverage test tells variants apart, the profile tables keep aggregating by name
+    std::string variant;
+    void set_variant(const char* fmt, ...);
     std::map<std::string, int> kid;
     std::vector<KStat> kstats;
     struct Rec {
@@ -215,5 +219,6 @@ struct Model {
         }                                                  \
         call;                                              \
         if (prof_open_) (m)->end();                        \
+        (m)->variant.clear();                              \
     } while (0)
 

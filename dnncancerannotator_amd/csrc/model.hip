@@ -101,12 +101,22 @@ int Model::alloc(void** ptr, size_t bytes) {
     return DNNCA_OK;
 }
 
+void Model::set_variant(const char* fmt, ...) {
+    char buf[64];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    variant = buf;
+}
+
 // ---------------------------------------------------------------------------------------------- launch accounting
 bool Model::begin(const char* name, double bytes, double flops) {
     if (dry) {
         char line[256];
-        snprintf(line, sizeof(line), "%s\t%.0f\t%.0f\n", name, bytes, flops);
+        snprintf(line, sizeof(line), "%s%s%s\t%.0f\t%.0f\n", name, variant.empty() ? "" : "#", variant.c_str(), bytes, flops);
         plan_text += line;
+        variant.clear();
         return false;
     }
     if (prof_mode == 0) return true;

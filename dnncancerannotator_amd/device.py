@@ -472,12 +472,13 @@ class DeviceModel:
             out.append((name.value.decode(), n.value, ms.value, by.value, fl.value))
         return out
 
-    def plan(self):
-        """The launch schedule of one train step at max_batch: [(kernel, algorithmic bytes, flops)]."""
+    def plan(self, variants=False):
+        """The launch schedule of one train step at max_batch: [(kernel, algorithmic bytes, flops)].  variants: keep the template
+        variant the library appends to a launch name (`ig_conv_fwd#3n2w8`): the kernel-coverage test tells them apart."""
         buf = C.create_string_buffer(1 << 20)
         check(self.lib.dnnca_plan_dump(self.handle, buf, len(buf)))
         out = []
         for line in buf.value.decode().splitlines():
             k, b, f = line.split('\t')
-            out.append((k, float(b), float(f)))
+            out.append((k if variants else k.split('#')[0], float(b), float(f)))
         return out

@@ -121,7 +121,7 @@ def run(device, f0, S, B=2, bn=False, cin=32, n_down=2):
     out = m.train_step(x, y, 0.0, m.loss_cfg(**cfg))
     g, gref = m.get_grads().astype(np.float64), O.flatten(spec, grads)
     errs = Hp.per_tensor_err(spec, g, gref)
-    names = sorted(set(r[0] for r in m.plan()))
+    names = sorted(set(r[0] for r in m.plan()) | set(r[0] for r in m.plan(variants=True)))
     m.close()
     deg = Hp.degenerate_tensors(spec)
     errs = {n: e for n, e in errs.items() if n not in deg}

@@ -25,7 +25,7 @@ ORACLE_TESTS = set()
 def record_oracle_plan(model_or_names, test):
     """`model_or_names`: a DeviceModel (its plan() -- the launch schedule of one train step under the current switches) or an
     iterable of launch names (a child process's); `test`: the registering test function's name."""
-    names = model_or_names if isinstance(model_or_names, (list, tuple, set)) else [r[0] for r in model_or_names.plan()]
+    names = model_or_names if isinstance(model_or_names, (list, tuple, set)) else [r[0] for r in model_or_names.plan(variants=True)]
     ORACLE_KERNELS.update(names)
     ORACLE_TESTS.add(test)
 

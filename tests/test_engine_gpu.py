@@ -269,6 +269,31 @@ def test_dense_configs_at_real_widths_against_oracle(gpu, arch, C, opts, B, size
     m.close()
 
 
+@pytest.mark.parametrize('alpha', [0.0, 0.99])
+def test_fp32_eight_wave_conv_kernels_against_oracle(gpu, alpha):
+    """k_ig_conv3<1, MODE, 8> / <2, MODE, 8> -- the eight-wave fp32 conv kernels of the 16- and 32-channel levels, forward and data
+    gradient -- are what configs/mulmo_unet.yaml runs at 8 x 512 x 512 (launch_ig picks them where a layer has >= 256 units of 32 x 16
+    pixels) and what no small shape selects: the kernel-coverage test found them missing.  Here a mulmo network of those widths runs
+    them on a 2 x 40 x 48 batch in a child process with DNNCA_IG_NW=8 (partial tiles in both directions), against the float64 oracle:
+    every variable within 2e-5 of its own scale + 10 x the float32-numpy noise (ReLU, perturbed weights; LeakyReLU(0.99) as the
+    flip-free companion, see test_dense_configs_at_real_widths_against_oracle)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    case = dict(arch='mulmo', C=3, opts=dict(n_filters_first=16, n_downsample=2, bn=True), B=2, H=40, W=48, alpha=alpha, seed=32)      # (seed 31 has a max-pool winner flip under LeakyReLU)
+    r = subprocess.run([sys.executable, os.path.join(here, 'oracle_case.py'), json.dumps(case)], env=dict(os.environ, DNNCA_IG_NW='8'),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    o = json.loads(r.stdout.strip().splitlines()[-1])
+    assert abs(o['loss'] - o['loss_ref']) <= 1e-4 * max(1.0, abs(o['loss_ref']))
+    bad = {n: e for n, e in o['errs'].items() if not e <= (2e-5 if not alpha else 1e-4) + o['floors'][n]}
+    assert not bad, bad
+    want = {'ig_conv_fwd#3n1w8', 'ig_conv_fwd#3n2w8', 'ig_conv_dgrad#3n1w8', 'ig_conv_dgrad#3n2w8'}
+    assert want <= set(o['plan']), o['plan']
+    Hp.record_oracle_plan(set(o['plan']) | set(k.split('#')[0] for k in o['plan']), 'test_fp32_eight_wave_conv_kernels_against_oracle')
+
+
 def _per_tensor_cosine(spec, g, gref):
     out = {}
     for n, sl in Hp.tensor_slices(spec):
