@@ -1,0 +1,105 @@
+// BatchNorm batch statistics that fold themselves (device side).
+//
+// The kernels that see every value a BatchNormalization normalises (the conv in front of it, components.py:56-59 -- or the
+// plain reduction pass where no producer can) leave per-block partial sums.  Folding those used to be a launch of its own
+// (k_bn_fold_stats: 8 .. 128 blocks, 8 us, plus a dependent launch on the step's critical chain, 24 / 48 times per step of the
+// dense configurations).  Here the producer folds: every block ADDS its partial sums to one of R bucket rows of a small table
+// (double atomics, global_atomic_add_f64: the sum of the float partials is exact to double rounding whatever the order, so the
+// result does not depend on the order the blocks arrive in; a row meets blocks / R adders), draws a ticket when it is done, and
+// the block that draws the last ticket folds the R rows, writes mean / variance / moving statistics / coefficients exactly as
+// g_bn_finalize does, and leaves table and ticket zeroed for the next user.  Table: Model::bn_tab (kBnTab doubles,
+// R * 2C <= kBnTab, R <= kBnRows), uses are stream-ordered.
+//
+// No device-scope fence: on gfx950 a release / acquire fence at agent scope is an L2 write-back / invalidate, and one per block
+// costs more than the reduction it guards (measured on k_bn_bwd_reduce_fast: 74 us against 25).  Nothing is published through
+// plain stores: the partial sums travel as device-scope atomic adds, a block waits for its adds to be performed before it draws
+// its ticket, and the last block reads the rows with device-scope loads.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dnnca {
+
+struct BnSelfFold {
+    double* tab;             // [R][2C] bucket rows: sums, then sums of squares; nullptr: no statistics wanted
+    unsigned* ticket;
+    int R, C;
+    float momentum, eps;
+    double n;                // values per channel
+    const float* gamma;
+    const float* beta;
+    float* mmean;
+    float* mvar;
+    float* coef;             // [4][C]: scale, shift, mean, 1 / sqrt(var + eps)
+};
+
+// bucket row of a contribution (key: anything spread evenly over the contributors, e.g. the block or tile index)
+constexpr int kBnRows = 16;          // bucket rows at most: the last block loads them all at once
+__device__ __forceinline__ double* bn_bucket(const BnSelfFold& f, int key) { return f.tab + (size_t)(key % f.R) * 2 * f.C; }
+
+// the R bucket values of column `col`, summed (device-scope loads, all in flight; rows past R: the last row again, not added)
+__device__ __forceinline__ double bn_fold_column(const double* tab, int R, int stride, int col) {
+    double v[kBnRows];
+#pragma unroll
+    for (int r = 0; r < kBnRows; ++r) v[r] = __hip_atomic_load(tab + (size_t)min(r, R - 1) * stride + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < kBnRows; ++r)
+        if (r < R) a += v[r];
+    return a;
+}
+
+// Is this block the last one of the launch to get here?  (block-uniform; all threads of every block call it once, after the
+// block's last bucket add; bid: linear block index, nblocks: blocks of the launch.)  Two levels of counters: the blocks of a
+// persistent kernel finish together, and same-address atomics execute one after the other (~56 ns each: 256 blocks on one counter
+// held the last one up for 14 us) -- so a block draws from one of kBnGroups group counters, and only the last of a group draws
+// from the top counter.  ticket[0]: top, ticket[1 + g]: groups; whoever draws the last ticket of a counter zeroes it.
+constexpr int kBnGroups = 16;
+__device__ __forceinline__ bool bn_last_block(unsigned* ticket, unsigned nblocks, unsigned bid) {
+    __shared__ unsigned bn_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // this thread's adds have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned G = nblocks < (unsigned)kBnGroups ? nblocks : (unsigned)kBnGroups, g = bid % G;
+        const unsigned members = (nblocks - g + G - 1) / G;
+        unsigned last = 0;
+        if (__hip_atomic_fetch_add(ticket + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            ticket[1 + g] = 0u;
+            if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+                ticket[0] = 0u;
+                last = 1u;
+            }
+        }
+        bn_last = last;
+    }
+    __syncthreads();
+    return bn_last != 0u;
+}
+
+// All threads of every block call this once, after the block's last bn_bucket() add.  nblocks / bid as for bn_last_block.
+__device__ __forceinline__ void bn_self_fold(const BnSelfFold& f, unsigned nblocks, unsigned bid) {
+    if (!bn_last_block(f.ticket, nblocks, bid)) return;
+    const int C = f.C, R = f.R;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        // everything this channel needs is requested at once: ONE memory round trip (as dependent load -> store pairs the moving
+        // statistics and gamma / beta cost four more, 2 us each, and held the producer's last block for 15 us)
+        const float gamma = f.gamma[c], beta = f.beta[c], mm = f.mmean[c], mv = f.mvar[c];
+        const double sum = bn_fold_column(f.tab, R, 2 * C, c), sumsq = bn_fold_column(f.tab, R, 2 * C, C + c);
+        for (int r = 0; r < R; ++r) { f.tab[(size_t)r * 2 * C + c] = 0.0; f.tab[(size_t)r * 2 * C + C + c] = 0.0; }
+        // raw moments -> coefficients and moving statistics: the contract of g_bn_finalize
+        const double mean_d = sum / f.n;
+        double var_d = sumsq / f.n - mean_d * mean_d;
+        if (var_d < 0.0) var_d = 0.0;
+        const float mean = (float)mean_d, var = (float)var_d;
+        const float unbiased = (float)(var_d * (f.n > 1.0 ? f.n / (f.n - 1.0) : 1.0));
+        f.mmean[c] = mm * f.momentum + mean * (1.f - f.momentum);
+        f.mvar[c] = mv * f.momentum + unbiased * (1.f - f.momentum);
+        const float inv = 1.0f / sqrtf(var + f.eps);
+        const float sc = gamma * inv;
+        f.coef[c] = sc;
+        f.coef[C + c] = beta - mean * sc;
+        f.coef[2 * C + c] = mean;
+        f.coef[3 * C + c] = inv;
+    }
+}
+
+}  // namespace dnnca

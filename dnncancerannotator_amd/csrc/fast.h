@@ -63,7 +63,10 @@ int ig_begin_backward(Model* m);
 void ig_release(Model* m);
 bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);   // bn_next: BatchNorm of the output whose statistics may ride in the epilogue
 bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
-bool bn_scratch(Model* m, size_t bytes, void** out);       // the model's BN partials table, grown on demand
+struct BnSelfFold;
+// batch statistics of BatchNorm `bn` folded by the kernel that produces its input (bn_dev.h): fills *f and marks the statistics as
+// taken care of (Op::fused_stats_rows); false: not available (the BatchNorm then runs its own reduction pass)
+bool bn_self_fold_args(Model* m, Op& bn, int B, BnSelfFold* f);
 bool ig_tconv_supported(const Model* m, const Op& o);
 bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);
 bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);   // decides maskA/maskB/premasked for every op (static per model)

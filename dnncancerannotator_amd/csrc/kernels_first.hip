@@ -6,6 +6,7 @@
 //     consecutive lanes covering consecutive channels of one pixel (NHWC: 16*G contiguous bytes per pixel).
 // The input needs no gradient, so backward is the weight (+bias) gradient only, with the act' mask applied on the fly
 // when the producer of dY did not already do so.
+#include "bn_dev.h"
 #include "fast.h"
 #include "kernels.h"
 
@@ -28,7 +29,7 @@ struct Args {
     float alpha;         // forward: activation slope (<0 none).  backward: slope of act' when `mask`
     int mask;
     int nbuckets, bucket_stride;     // backward: block b adds into copy b % nbuckets (copies bucket_stride floats apart)
-    float* bn_part;      // forward: [blocks][2 CO] partial sums / sums of squares of the output for the BatchNorm behind it (or nullptr)
+    BnSelfFold bnf;      // forward: batch statistics of the output for the BatchNorm behind it, self-folding (bn_dev.h; tab == nullptr: none)
 };
 
 __device__ __forceinline__ void stage_patch(const Args& p, float* xs, int b, int y0, int x0) {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_first_fwd(Args p) {
             bq.x = fmaf(a.x, a.x, bq.x); bq.y = fmaf(a.y, a.y, bq.y); bq.z = fmaf(a.z, a.z, bq.z); bq.w = fmaf(a.w, a.w, bq.w);
         }
     }
-    if (p.bn_part) {        // one partial row per block: [sums (CO), sums of squares (CO)] (the layout of the conv kernels' rows)
+    if (p.bnf.tab) {        // the block's sums go to one bucket row: [sums (CO), sums of squares (CO)]
         red[threadIdx.x][0] = bs.x; red[threadIdx.x][1] = bs.y; red[threadIdx.x][2] = bs.z; red[threadIdx.x][3] = bs.w;
         red[threadIdx.x][4] = bq.x; red[threadIdx.x][5] = bq.y; red[threadIdx.x][6] = bq.z; red[threadIdx.x][7] = bq.w;
         __syncthreads();
@@ -82,8 +83,9 @@ __global__ __launch_bounds__(256) void k_first_fwd(Args p) {
             const int c = o % p.CO, which = o / p.CO;
             float acc = 0.f;
             for (int l = 0; l < PL; ++l) acc += red[l * G + (c >> 2)][4 * which + (c & 3)];
-            p.bn_part[(size_t)blockIdx.x * 2 * p.CO + o] = acc;
+            atomicAdd(bn_bucket(p.bnf, (int)blockIdx.x) + o, (double)acc);
         }
+        bn_self_fold(p.bnf, gridDim.x, blockIdx.x);
     }
 }
 
@@ -192,15 +194,8 @@ bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op*
     first::Args a = first_args(m, B, o);
     a.alpha = o.alpha;
     const int blocks = a.ntiles < 4096 ? a.ntiles : 4096;
-    if (bn_next && !getenv("DNNCA_NO_BN_FUSION")) {      // the BatchNorm behind this conv takes its batch statistics from here
-        void* part = nullptr;
-        if (m->dry) {
-            bn_next->fused_stats_rows = blocks;
-        } else if (bn_scratch(m, (size_t)blocks * 2 * a.CO * 4, &part)) {
-            a.bn_part = (float*)part;
-            bn_next->fused_stats_rows = blocks;
-        }
-    }
+    if (bn_next && !getenv("DNNCA_NO_BN_FUSION"))       // the BatchNorm behind this conv takes its batch statistics from here
+        (void)bn_self_fold_args(m, *bn_next, B, &a.bnf);
     LAUNCH(m, "first_fwd", bytes, flops, hipLaunchKernelGGL(first::k_first_fwd, dim3(blocks), dim3(256), 0, m->stream, a));
     return true;
 }

@@ -10,6 +10,7 @@
 // The data gradient is the forward kernel on a transposed + flipped copy of the weights (k_ig_flip, once per step).
 #include <type_traits>
 
+#include "bn_dev.h"
 #include "fast.h"
 #include "kernels.h"
 
@@ -47,8 +48,9 @@ struct ConvArgs {
     int B, H, W;
     int tiles_x, tiles_y;
     float alpha;             // forward: activation slope (<0 none); data gradient: slope of the masked activation
-    // forward: batch statistics of the BatchNorm behind this conv ride in the epilogue of the persistent kernels:
-    float* bn_part;          // [tile][2 * Cout] float partials (sum, sum of squares per channel); nullptr: none
+    // forward: batch statistics of the BatchNorm behind this conv ride in the epilogue of the persistent kernels, which fold them
+    // themselves (bn_dev.h; bnf.tab == nullptr: none)
+    BnSelfFold bnf;
     int src_half;            // the sources are stored as bf16 (View::h; k_igb_conv3 only)
     int dst_half;            // forward, persistent kernels: dst[0] is stored as bf16 (the input of a BatchNorm, ig_plan_half)
     int dsth[2];             // data gradient, persistent kernels: dst[k] is stored as bf16 (the gradient arriving at a BatchNorm)
@@ -58,7 +60,7 @@ struct ConvArgs {
 // of wave w holds acc[r][j][i] = pixel (row 4w + r, column 4q + i) x channel 16j + m16 of the 16 x 16 tile, so one store
 // instruction writes four 64-byte channel runs.  (The earlier version transposed the tile through LDS to store 256-byte rows:
 // 64 LDS writes + 16 LDS reads per lane and up to five barriers cost as much as 1.7 K-chunks of MFMAs per tile.)
-//   MODE 0: + bias, activation; the BatchNorm behind the conv takes its batch statistics from here (ConvArgs::bn_part): per-lane
+//   MODE 0: + bias, activation; the BatchNorm behind the conv takes its batch statistics from here (ConvArgs::bnf): per-lane
 //           sums over the lane's 16 pixels, the four q groups folded by two wave shuffles, the NW waves through `red`
 //           ([NW][2 COT] floats of LDS) -- one barrier;
 //   MODE 1: accumulate into dst and multiply by act'(mask tensor) as requested.
@@ -74,7 +76,7 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
     const int which = co0 >= p.n_dst0;
     const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co0 - p.n_dst0 : co0;
     float* dst = p.dst[which];
-    const bool bn_on = MODE == 0 && p.bn_part != nullptr;
+    const bool bn_on = MODE == 0 && p.bnf.tab != nullptr;
     float bias[NN], bs[NN], bq[NN];
 #pragma unroll
     for (int j = 0; j < NN; ++j) {
@@ -166,7 +168,7 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
             for (int j = 0; j < NN; ++j)
                 if (ok[i]) dst[o[i] + 16 * j] = v[i][j];
     }
-    if (bn_on) {        // partial row of this unit: [tile][2 cw]: first half sums, second half sums of squares
+    if (bn_on) {        // this unit's sums go to bucket row tile % R: [2 cw], first half sums, second half sums of squares
 #pragma unroll
         for (int j = 0; j < NN; ++j) {
             bs[j] += __shfl_xor(bs[j], 16); bs[j] += __shfl_xor(bs[j], 32);
@@ -182,7 +184,7 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
 #pragma unroll
             for (int w = 0; w < NW; ++w) a += red[w * (2 * COT) + tid];
             const int half = tid >= COT, c = half ? tid - COT : tid;
-            p.bn_part[(size_t)tile * (2 * cw) + half * cw + cl + c] = a;
+            atomicAdd(bn_bucket(p.bnf, tile) + half * cw + cl + c, (double)a);
         }
     }
 }
@@ -599,7 +601,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
     const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
     const int my_units = (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nitems = my_units * nchunks;
-    if (nitems <= 0) return;
+    if (nitems <= 0) {          // (the launchers size the grid to the units: not reached)
+        if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);
+        return;
+    }
 
     const size_t npix = (size_t)p.B * p.H * p.W;
     const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * 4), nbytes1 = (unsigned)(npix * p.c_src1 * 4);
@@ -752,6 +757,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
             conv3_epilogue<NN, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
         }
     }
+    if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);          // block-uniform; every block gets here
 }
 
 // ------------------------------------------------------------------------------------------------ transposed conv 2x2/2
@@ -773,7 +779,7 @@ struct TcArgs {
     int npix;                // B*H*W
     int psplit;
     float alpha;
-    float* bn_part;          // forward (bf16 kernel): [pixel block][2 * cout] partial batch statistics of the output for the BatchNorm behind it
+    BnSelfFold bnf;          // forward (bf16 kernel): batch statistics of the output for the BatchNorm behind it, self-folding (bn_dev.h)
     int out_half;            // forward (bf16 kernel): out is stored as bf16 (the input of a BatchNorm, ig_plan_half)
     int din_half;            // data gradient (bf16 kernel): din is stored as bf16 (the gradient arriving at a BatchNorm)
 };
@@ -1390,7 +1396,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_igb_conv3(ConvArgs p, const
     const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
     const int my_units = (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nitems = my_units * nchunks;
-    if (nitems <= 0) return;
+    if (nitems <= 0) {          // (the launchers size the grid to the units: not reached)
+        if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);
+        return;
+    }
 
     const size_t npix = (size_t)p.B * p.H * p.W;
     constexpr unsigned ESZ = A16 ? 2 : 4;
@@ -1583,6 +1592,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_igb_conv3(ConvArgs p, const
             IGSTAMP(it - 1, 7);
         }
     }
+    if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);          // block-uniform; every block gets here
 }
 
 // weight gradient, bf16, 64 x 64 channel blocks (all unet_big layers): M = 64 input channels (16 per wave), N = 64
@@ -1764,9 +1774,6 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
     constexpr int XU = (PATCH * 16 + 511) / 512, GU = TY * TX * 16 / 512;      // 6 and 4 8-byte elements per thread
     const FastDiv d_tx(p.tiles_x), d_ty(p.tiles_y);
     bf16x4 xr[XU], gr[GU];
-    const bf16_t* x16 = reinterpret_cast<const bf16_t*>(p.x);
-    const bf16_t* g16 = reinterpret_cast<const bf16_t*>(p.dz);
-    const bf16x4 zero4 = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
     // Buffer loads with 32-bit byte offsets: what depends on the thread (patch pixel, channel quad) is computed once, a tile adds
     // one wave-uniform base; pixels outside the image get an out-of-range offset and come back as zeros (the staging of a
     // tile was ~150 vector instructions per wave with 64-bit address arithmetic: a fifth of the kernel).
@@ -1964,7 +1971,7 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t
                 }
             }
         }
-    if (p.bn_part) {        // batch statistics for the BatchNorm behind the transposed conv: one row per pixel block
+    if (p.bnf.tab) {        // batch statistics for the BatchNorm behind the transposed conv: a bucket row per pixel block
         __shared__ float red[4][128];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1976,8 +1983,9 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t
         if (tid < 128) {
             const float a = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
             const int half = tid >> 6, c = tid & 63;
-            p.bn_part[(size_t)blockIdx.x * (2 * p.cout) + half * p.cout + co0 + c] = a;
+            atomicAdd(bn_bucket(p.bnf, (int)blockIdx.x) + half * p.cout + co0 + c, (double)a);
         }
+        bn_self_fold(p.bnf, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
     }
 }
 
@@ -2394,7 +2402,6 @@ static int ig_waves(const ig::ConvArgs& a, int cout) {
     const long units8 = (long)((a.W + 15) / 16) * ((a.H + 31) / 32) * a.B * (cout / (16 * nn3));
     return (forced == 8 || units8 >= 256) ? 8 : 4;
 }
-static int conv3_rows(const ig::ConvArgs& a, int tile_rows) { return ((a.W + 15) / 16) * ((a.H + tile_rows - 1) / tile_rows) * a.B; }
 
 template <int MODE>
 static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* name, double bytes, double flops) {
@@ -2466,15 +2473,8 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
     a.src_half = o.inA.d.h;          // ig_plan_half keeps both sources of a conv in the same format
     a.dst_half = o.out.d.h;
     if (bn_next && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
-        // the BatchNorm behind this conv takes its batch statistics from the conv's epilogue
-        const int rows = conv3_rows(a, 4 * (use_bf16(m, o) ? igb_waves(a, o.out.d.C) : ig_waves(a, o.out.d.C)));     // one partial row per pixel tile
-        void* part = nullptr;
-        if (m->dry) {
-            bn_next->fused_stats_rows = rows;          // the dry run lists the launches of the real one
-        } else if (bn_scratch(m, (size_t)rows * 2 * o.out.d.C * 4, &part)) {
-            a.bn_part = (float*)part;
-            bn_next->fused_stats_rows = rows;
-        }
+        // the BatchNorm behind this conv takes its batch statistics (and coefficients) from the conv's epilogue
+        (void)bn_self_fold_args(m, *bn_next, B, &a.bnf);
     }
     if (a.src_half && !(use_bf16(m, o) && conv3_path(a, o.out.d.C, true))) return false;      // cannot happen (ig_plan_half); the caller reports it
     if (use_bf16(m, o)) {
@@ -2647,16 +2647,8 @@ bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_nex
     ig::TcArgs a = tc_args(m, B, o);
     if (use_bf16_tc(m, o)) {
         IgPlan& pl = g_ig[m];
-        if (bn_next && !getenv("DNNCA_NO_BN_FUSION")) {      // batch statistics of the BatchNorm behind it ride in the epilogue
-            const int rows = (a.npix + 127) / 128;
-            void* part = nullptr;
-            if (m->dry) {
-                bn_next->fused_stats_rows = rows;
-            } else if (bn_scratch(m, (size_t)rows * 2 * a.cout * 4, &part)) {
-                a.bn_part = (float*)part;
-                bn_next->fused_stats_rows = rows;
-            }
-        }
+        if (bn_next && !getenv("DNNCA_NO_BN_FUSION"))       // batch statistics of the BatchNorm behind it ride in the epilogue
+            (void)bn_self_fold_args(m, *bn_next, B, &a.bnf);
         const dim3 grid((a.npix + 127) / 128, a.cout / 64);
         m->set_variant("h%d", (int)(o.inA.d.h != 0));
         if (o.inA.d.h)

@@ -2360,10 +2360,10 @@ bool fast_tail3(Model* m, int B, Op& o, Op& head, const float* y, const dnnca_lo
     const int ntasks = B * nchunks * a.nstrips, nblk = (ntasks + 3) / 4;
     if (nblk > 2048) return false;                      // rows of the head's partials table
     const double npx = (double)B * H * W;
-    static const int variant = getenv("DNNCA_TAIL3_VARIANT") ? atoi(getenv("DNNCA_TAIL3_VARIANT")) : 0;      // tuning aid
     static const int tail3_lds = getenv("DNNCA_TAIL3_LDS") ? atoi(getenv("DNNCA_TAIL3_LDS")) : 0;      // tuning aid: dynamic LDS bytes (limits blocks per CU)
     auto kern = k_tail3<3, 27, true, 0, 1>;
 #ifdef DNNCA_TUNING
+    static const int variant = getenv("DNNCA_TAIL3_VARIANT") ? atoi(getenv("DNNCA_TAIL3_VARIANT")) : 0;      // tuning aid
     if (variant == 1) kern = k_tail3<3, 27, true>;
     if (variant == 2) kern = k_tail3<6, 27, true>;
     if (variant == 3) kern = k_tail3<3, 0, true>;

@@ -604,10 +604,12 @@ bool fast_label_stats(Model* m, size_t n, const float* y) {
 // ================================================================================================ batch normalisation
 // Tuned BatchNormalization for C % 4 == 0 with (C/4) | 256 (16..1024 channels): one thread owns a 4-channel group of a
 // pixel (16-byte loads, several in flight), the 256/(C/4) pixel lanes of a block walk chunks of pixels dealt round-robin,
-// partial sums meet in LDS and leave the block as one row of a [blocks][2C] partials table (same-address atomics from
-// hundreds of blocks cost more than the whole read pass: tools/micro/bn_reduce.hip).  A second small kernel folds the
-// table: forward -> mean / biased variance / moving statistics / coefficients (raw moments, accumulated in double),
-// backward -> dgamma / dbeta.
+// partial sums meet in LDS and leave the block as atomic adds to one of a few bucket rows (same-address atomics from
+// hundreds of blocks cost more than the whole read pass: tools/micro/bn_reduce.hip); the last block to finish folds the rows
+// (bn_dev.h): forward -> mean / biased variance / moving statistics / coefficients (raw moments, folded in double),
+// backward -> dgamma / dbeta.  No fold launch.
+#include "bn_dev.h"
+
 namespace dnnca {
 
 // four consecutive channels of a tensor stored as f32 or (View::h) as bf16; `elem` is the element offset
@@ -624,7 +626,7 @@ __device__ __forceinline__ float4 ld4(const float* base, size_t elem) {
 static inline bool bn_fast_ok(const View& x) { return x.ps == x.C && x.C % 4 == 0 && 256 % (x.C / 4) == 0 && x.C >= 16; }
 
 template <bool XH>      // XH: x is stored as bf16
-__global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float* __restrict__ x, int C, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float* __restrict__ x, int C, BnSelfFold f) {
     __shared__ double red[256][8];
     const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
     double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
@@ -658,97 +660,14 @@ __global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float*
     for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = ds[i]; red[threadIdx.x][4 + i] = dq[i]; }
     __syncthreads();
     // 2C outputs (sum, sumsq per channel), PL terms each
+    double* row = bn_bucket(f, (int)blockIdx.x);
     for (int o = threadIdx.x; o < 2 * C; o += 256) {
         const int c = o % C, which = o / C;
         double a = 0.0;
         for (int l = 0; l < PL; ++l) a += red[l * G + (c >> 2)][4 * which + (c & 3)];
-        part[(size_t)blockIdx.x * 2 * C + o] = a;
+        atomicAdd(row + o, a);
     }
-}
-
-// fold of a [nb][2C] partials table: block = CPB channels x 1024/CPB row lanes, grid = ceil(C / CPB).  CPB = 32 for the
-// few hundred rows the reduction kernels leave, 8 (more blocks, more rows in flight) for the per-tile rows a conv epilogue
-// leaves (thousands).  The result (two sums per channel) lands in the first CPB threads.
-template <int CPB, typename TP>
-__device__ __forceinline__ void bn_fold(const TP* __restrict__ part, int nb, int C, double& a0, double& a1, double* red) {
-    constexpr int RL = 1024 / CPB;
-    const int cl = threadIdx.x % CPB, r = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
-    double s0 = 0.0, s1 = 0.0;
-    if (c < C) {
-        // eight rows (sixteen loads) in flight per thread: the fold is a chain of memory round trips, not bandwidth
-        constexpr int U = 8;
-        for (int b = r; b < nb; b += U * RL) {
-            TP v0[U], v1[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {       // rows past the end: the last row again, not added
-                const int bb = min(b + u * RL, nb - 1);
-                v0[u] = part[(size_t)bb * 2 * C + c];
-                v1[u] = part[(size_t)bb * 2 * C + C + c];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (b + u * RL < nb) { s0 += (double)v0[u]; s1 += (double)v1[u]; }
-        }
-    }
-    red[(r * CPB + cl) * 2] = s0;
-    red[(r * CPB + cl) * 2 + 1] = s1;
-    __syncthreads();
-    a0 = 0.0; a1 = 0.0;
-    if constexpr (RL > 32) {          // two levels: row lanes 0..7 fold RL/8 lanes each, lane 0 folds those eight
-        constexpr int SUB = RL / 8;
-        double t0 = 0.0, t1 = 0.0;
-        if (r < 8) {
-#pragma unroll 8
-            for (int l = r * SUB; l < (r + 1) * SUB; ++l) { t0 += red[(l * CPB + cl) * 2]; t1 += red[(l * CPB + cl) * 2 + 1]; }
-        }
-        __syncthreads();
-        if (r < 8) { red[(r * CPB + cl) * 2] = t0; red[(r * CPB + cl) * 2 + 1] = t1; }
-        __syncthreads();
-        if (r == 0)
-#pragma unroll
-            for (int l = 0; l < 8; ++l) { a0 += red[(l * CPB + cl) * 2]; a1 += red[(l * CPB + cl) * 2 + 1]; }
-    } else {
-        if (r == 0)
-#pragma unroll 8
-            for (int l = 0; l < RL; ++l) { a0 += red[(l * CPB + cl) * 2]; a1 += red[(l * CPB + cl) * 2 + 1]; }
-    }
-}
-
-// raw moments -> coefficients (and the moving statistics in training): same contract as g_bn_finalize
-template <int CPB, typename TP>
-__global__ __launch_bounds__(1024) void k_bn_fold_stats(int C, int nb, double n, const TP* __restrict__ part,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* __restrict__ mmean, float* __restrict__ mvar,
-                                                        float* __restrict__ coef, float momentum, float eps) {
-    __shared__ double red[2048];
-    double sum, sumsq;
-    bn_fold<CPB>(part, nb, C, sum, sumsq, red);
-    const int c = blockIdx.x * CPB + (int)(threadIdx.x % CPB);
-    if (threadIdx.x >= CPB || c >= C) return;
-    const double mean_d = sum / n;
-    double var_d = sumsq / n - mean_d * mean_d;
-    if (var_d < 0.0) var_d = 0.0;
-    const float mean = (float)mean_d, var = (float)var_d;
-    const float unbiased = (float)(var_d * (n > 1.0 ? n / (n - 1.0) : 1.0));
-    mmean[c] = mmean[c] * momentum + mean * (1.f - momentum);
-    mvar[c] = mvar[c] * momentum + unbiased * (1.f - momentum);
-    const float inv = 1.0f / sqrtf(var + eps);
-    const float sc = gamma[c] * inv;
-    coef[c] = sc;
-    coef[C + c] = beta[c] - mean * sc;
-    coef[2 * C + c] = mean;
-    coef[3 * C + c] = inv;
-}
-
-__global__ __launch_bounds__(1024) void k_bn_fold_bwd(int C, int nb, const float* __restrict__ part, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta) {
-    __shared__ double red[2048];
-    double g, b;
-    bn_fold<8>(part, nb, C, g, b, red);          // 8 channels x 128 row lanes per block: at most four rows per thread for 512 rows
-    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
-    if ((threadIdx.x >> 3) != 0 || c >= C) return;
-    dgamma[c] += (float)g;
-    dbeta[c] += (float)b;
+    bn_self_fold(f, gridDim.x, blockIdx.x);
 }
 
 template <bool YH, bool XH>      // YH / XH: y / x is stored as bf16
@@ -831,10 +750,16 @@ __global__ __launch_bounds__(256) void k_pool2_bwd_idx(size_t nwin4, const float
     }
 }
 
+// Sums of one BatchNorm backward (dgamma = sum dy * xhat, dbeta = sum dy) -- and their fold: every block adds its 2C partial sums
+// to one of R bucket rows (double atomics, bn_dev.h; a row meets gridDim / R blocks), takes a ticket, and the block that draws the
+// last one folds the R rows, adds the result to dgamma / dbeta and leaves rows and ticket zeroed for the next BatchNorm.
+// No fold launch between this pass and the apply pass (it was a 9 us kernel of 8 .. 128 blocks plus a dependent launch, 24 / 48
+// times per step of the dense configurations).
 template <bool XH, bool GH>      // XH / GH: x / dy is stored as bf16
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const float* __restrict__ x, const float* __restrict__ dy,
                                                             int C, int dps, const float* __restrict__ coef,
-                                                            float* __restrict__ part) {
+                                                            double* __restrict__ tab, int R, unsigned* __restrict__ ticket,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float red[256][8];
     const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
     const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
@@ -869,11 +794,23 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
         }
     for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = sg[i]; red[threadIdx.x][4 + i] = sb[i]; }
     __syncthreads();
+    double* row = tab + (size_t)(blockIdx.x % R) * 2 * C;
     for (int o = threadIdx.x; o < 2 * C; o += 256) {
         const int c = o % C, which = o / C;
         float a = 0.f;
         for (int l = 0; l < PL; ++l) a += red[l * G + (c >> 2)][4 * which + (c & 3)];
-        part[(size_t)blockIdx.x * 2 * C + o] = a;
+        atomicAdd(row + o, (double)a);
+    }
+    // ticket: a block's adds have been performed (device-scope atomics, waited for) before its ticket is drawn; the last block reads
+    // the rows with device-scope loads.  No device-scope FENCE anywhere: on gfx950 that is an L2 write-back / invalidate per block,
+    // and 512 of them cost more than the reduction (74 us against 25); nothing here is published through plain stores.
+    if (!bn_last_block(ticket, gridDim.x, blockIdx.x)) return;
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        float* dst = o < C ? dgamma + o : dbeta + (o - C);
+        const float before = *dst;          // requested together with the rows: one memory round trip
+        const double a = bn_fold_column(tab, R, 2 * C, o);
+        for (int r = 0; r < R; ++r) tab[(size_t)r * 2 * C + o] = 0.0;
+        *dst = before + (float)a;
     }
 }
 
@@ -910,15 +847,30 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
     else *o = r;
 }
 
-// partials table shared by all BN ops of a model (stream-ordered use); grown on demand
-bool bn_scratch(Model* m, size_t bytes, void** out) {
-    if (bytes > m->bn_part_bytes) {
-        void* p = nullptr;
-        if (m->alloc(&p, bytes) != DNNCA_OK) return false;
-        m->bn_part = p;
-        m->bn_part_bytes = bytes;
+static bool bn_table(Model* m) {          // arrives zeroed, stays zeroed between uses
+    return m->bn_tab || m->alloc((void**)&m->bn_tab, (size_t)(Model::kBnTab + 16) * 8) == DNNCA_OK;          // + the ticket counters
+}
+
+bool bn_self_fold_args(Model* m, Op& bn, int B, BnSelfFold* f) {
+    const int C = bn.inA.d.C;
+    if (2 * C > Model::kBnTab) return false;
+    if (!m->dry) {          // (the dry run lists the launches of the real one)
+        if (!bn_table(m)) return false;
+        const int R = Model::kBnTab / (2 * C);
+        f->tab = m->bn_tab;
+        f->ticket = reinterpret_cast<unsigned*>(m->bn_tab + Model::kBnTab);
+        f->R = R > kBnRows ? kBnRows : R;
+        f->C = C;
+        f->momentum = kBnMomentum;
+        f->eps = kBnEps;
+        f->n = (double)B * bn.inA.d.H * bn.inA.d.W;
+        f->gamma = m->p + bn.w_off;
+        f->beta = m->p + bn.b_off;
+        f->mmean = m->state + bn.mm_off;
+        f->mvar = m->state + bn.mv_off;
+        f->coef = bn.coef;
     }
-    *out = m->bn_part;
+    bn.fused_stats_rows = 1;
     return true;
 }
 #define DN_TRYB(x) do { if (!(x)) return false; } while (0)
@@ -944,33 +896,19 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
     const double tb = 4.0 * npix * C;
     if (training) {
         if (o.fused_stats_rows > 0) {
-            // the producing conv left [rows][2C] float partials in the partials table (its epilogue saw every output value)
-            const int rows = o.fused_stats_rows;
+            // the kernel that produced the input saw every value and has left the coefficients (bn_self_fold_args)
             o.fused_stats_rows = 0;
-            if (C <= 64)       // few channels: fewer channels per block, more row lanes
-                LAUNCH(m, "bn_fold_stats", 8.0 * rows * C, 0,
-                       hipLaunchKernelGGL((k_bn_fold_stats<2, float>), dim3((C + 1) / 2), dim3(1024), 0, m->stream, C, rows, (double)npix,
-                                          (const float*)m->bn_part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,
-                                          m->state + o.mv_off, o.coef, momentum, eps));
-            else
-                LAUNCH(m, "bn_fold_stats", 8.0 * rows * C, 0,
-                       hipLaunchKernelGGL((k_bn_fold_stats<8, float>), dim3((C + 7) / 8), dim3(1024), 0, m->stream, C, rows, (double)npix,
-                                          (const float*)m->bn_part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,
-                                          m->state + o.mv_off, o.coef, momentum, eps));
         } else {
             const unsigned nb = bn_blocks(npix, C);
-            double* part = nullptr;
-            DN_TRYB(bn_scratch(m, (size_t)nb * 2 * C * 8, (void**)&part));
+            BnSelfFold f{};
+            DN_TRYB(bn_self_fold_args(m, o, B, &f));
+            o.fused_stats_rows = 0;
             if (o.inA.d.h)
                 LAUNCH(m, "bn_stats", tb / 2, 3 * tb / 4,
-                       hipLaunchKernelGGL(k_bn_stats_fast<true>, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, part));
+                       hipLaunchKernelGGL(k_bn_stats_fast<true>, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, f));
             else
                 LAUNCH(m, "bn_stats", tb, 3 * tb / 4,
-                       hipLaunchKernelGGL(k_bn_stats_fast<false>, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, part));
-            LAUNCH(m, "bn_fold_stats", 16.0 * nb * C, 0,
-                   hipLaunchKernelGGL((k_bn_fold_stats<32, double>), dim3((C + 31) / 32), dim3(1024), 0, m->stream, C, (int)nb, (double)npix,
-                                      (const double*)part, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off, m->state + o.mv_off,
-                                      o.coef, momentum, eps));
+                       hipLaunchKernelGGL(k_bn_stats_fast<false>, dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, C, f));
         }
     } else {
         LAUNCH(m, "g_bn_finalize", 0, 0,
@@ -1016,19 +954,19 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
     const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
     const double tb = 4.0 * npix * C;
     const unsigned nb = bn_blocks(npix, C);
-    float* part = nullptr;
-    DN_TRYB(bn_scratch(m, (size_t)nb * 2 * C * 8, (void**)&part));
+    if (!m->dry) DN_TRYB(bn_table(m));
+    int R = Model::kBnTab / (2 * C);          // C <= 1024 (bn_fast_ok): at least two rows
+    if (R > kBnRows) R = kBnRows;
+    if (R > (int)nb) R = (int)nb;
+    unsigned* ticket = reinterpret_cast<unsigned*>(m->bn_tab + Model::kBnTab);
     const bool xh = o.inA.d.h != 0, gh = o.out.g.h != 0, dh = o.inA.g.h != 0;
     const double rb = tb * ((xh ? 0.5 : 1.0) + (gh ? 0.5 : 1.0));
 #define BNRED(XHv, GHv) LAUNCH(m, "bn_bwd_reduce", rb, tb,                                                                   \
         hipLaunchKernelGGL((k_bn_bwd_reduce_fast<XHv, GHv>), dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C, \
-                           o.out.g.ps, o.coef, part))
+                           o.out.g.ps, o.coef, m->bn_tab, R, ticket, m->g + o.w_off, m->g + o.b_off))
     if (xh) { if (gh) BNRED(true, true); else BNRED(true, false); }
     else { if (gh) BNRED(false, true); else BNRED(false, false); }
 #undef BNRED
-    LAUNCH(m, "bn_fold_bwd", 8.0 * nb * C, 0,
-           hipLaunchKernelGGL(k_bn_fold_bwd, dim3((C + 7) / 8), dim3(1024), 0, m->stream, C, (int)nb, part, m->g + o.w_off,
-                              m->g + o.b_off));
     const size_t n4 = npix * (C / 4);
     const dim3 grid((unsigned)((n4 + 255) / 256));
 #define BNBWD(DHv, XHv, GHv) LAUNCH(m, "bn_bwd_apply", rb + tb * (DHv ? 0.5 : 1.0), 2 * tb,                                  \

@@ -59,6 +59,9 @@ struct KStat {
     double total_ms = 0, bytes = 0, flops = 0;
 };
 
+constexpr float kBnMomentum = 0.99f;   // Keras BatchNormalization defaults [TF-2.6]
+constexpr float kBnEps = 1e-3f;
+
 struct Model {
     dnnca_model_desc desc;
     int device = 0;
@@ -91,8 +94,9 @@ struct Model {
     hipEvent_t aug_ev[kAugRing] = {nullptr, nullptr, nullptr, nullptr};      // recorded behind the upload that read row k
     int aug_k = 0;
     float* first_slabs = nullptr;        // bucket copies of the first-layer weight gradient (kernels_first.hip; kept zeroed)
-    void* bn_part = nullptr;             // partials table of the tuned BN reductions (kernels_misc.hip)
-    size_t bn_part_bytes = 0;
+    // bucket rows of the BN reductions that fold themselves (bn_dev.h): kBnTab doubles, then the ticket counter; kept zeroed
+    static constexpr int kBnTab = 4096;
+    double* bn_tab = nullptr;
     float* extra_zero = nullptr;         // buffer the tuned kernels need zeroed at the top of every backward pass
     size_t extra_zero_n = 0;
     float* head_partials = nullptr;      // [2048][8] block partials of the fused head kernel

@@ -26,8 +26,6 @@ void set_error(const char* fmt, ...) {
 }
 
 enum { kScalars = 8 };
-static constexpr float kBnMomentum = 0.99f;   // Keras BatchNormalization defaults [TF-2.6]
-static constexpr float kBnEps = 1e-3f;
 
 Model::~Model() {
     fast_release(this);
