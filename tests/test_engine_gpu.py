@@ -269,6 +269,40 @@ def test_dense_configs_at_real_widths_against_oracle(gpu, arch, C, opts, B, size
     m.close()
 
 
+def test_batchnorm_reductions_fold_themselves_repeatably(gpu):
+    """The BatchNorm reductions add their partial sums to a small table with double atomics and the last block of the same launch
+    folds it and leaves it zeroed (csrc/bn_dev.h).  Ten steps at learning rate 0 on one model: every step finds the table zeroed (a
+    leftover would show up in the very next BatchNorm's statistics), so every step reproduces the first one's loss, BatchNorm
+    gradients and batch statistics -- the double sums of float partials do not depend on the order the blocks arrive in (what is
+    allowed to move is the float32 weight-gradient atomics of the convs)."""
+    opts = dict(n_filters_first=64, n_downsample=2, rate=2, kernel_size=3, conv_stride=1, bn=True, padding='same')
+    B, S = 2, 64
+    spec = O.ModelSpec('unet', 1, **opts)
+    rng = np.random.default_rng(5)
+    x = rng.random((B, S, S, 1)).astype(np.float32)
+    y = (rng.random((B, S, S)) < 0.05).astype(np.float32)
+    for dtype in ('f32', 'bf16'):
+        m = gpu.DeviceModel('unet', 1, S, S, B, dtype=dtype, **opts)
+        m.init_glorot(seed=4)
+        s0 = m.get_state()
+        cfg = m.loss_cfg(weight_mul=3.0)
+        first = None
+        for step in range(10):
+            m.set_state(s0)
+            out = m.train_step(x, y, 0.0, cfg)
+            g, st = m.get_grads().astype(np.float64), m.get_state().astype(np.float64)
+            bn = np.concatenate([g[sl] for n, sl in Hp.tensor_slices(spec) if n.endswith('.gamma') or n.endswith('.beta')])
+            if first is None:
+                first = (out.loss, bn, st)
+                assert np.isfinite(bn).all() and np.abs(bn).max() > 0
+                continue
+            assert abs(out.loss - first[0]) <= 1e-6 * max(1.0, abs(first[0])), (dtype, step)
+            assert np.abs(st - first[2]).max() <= 1e-6 * np.abs(first[2]).max(), (dtype, step)          # moving statistics
+            assert np.abs(bn - first[1]).max() <= 1e-4 * np.abs(first[1]).max(), (dtype, step)          # (their inputs carry the conv atomics)
+        assert 'bn_bwd_reduce' in set(r[0] for r in m.plan())
+        m.close()
+
+
 @pytest.mark.parametrize('alpha', [0.0, 0.99])
 def test_fp32_eight_wave_conv_kernels_against_oracle(gpu, alpha):
     """k_ig_conv3<1, MODE, 8> / <2, MODE, 8> -- the eight-wave fp32 conv kernels of the 16- and 32-channel levels, forward and data
