@@ -1750,28 +1750,35 @@ __global__ __launch_bounds__(256, 1) void k_igb_wgrad64(ig::WgArgs p) {
 // gradient: the atomic traffic is unchanged.
 // Two LDS buffers: the next tile (in registers since the previous iteration) is written into the other buffer while this one is
 // consumed -- one barrier per tile and no wave waits for the commit.
+// NJ = 16-channel output tiles per wave (2: the block covers 64 output channels).  NJ = 4 -- 128 output channels per block, the
+// same X patch and nine A fragments serving twice the MFMAs (26 transposing reads per 36 MFMAs instead of 22 per 18), half as
+// many split-K blocks per (ci, co) pair, so half the atomic drain and half the dY re-reads -- was built and measured in round 3:
+// 253 registers (no spills), 114.5 us per launch against 94.8 and unet_big 7.73 against 6.88 ms: with 144 accumulators the
+// compiler has no registers left to keep fragment reads ahead of the MFMAs.  Not instantiated.
+template <int NJ>
 __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
+    constexpr int COB = 32 * NJ;                // output channels per block
+    constexpr int GRS = COB + 16;               // bf16 per staged dY pixel row
     __shared__ __attribute__((aligned(16))) bf16_t ximg2[2][PATCH * WRS];
-    __shared__ __attribute__((aligned(16))) bf16_t gimg2[2][TY * TX * WRS];
+    __shared__ __attribute__((aligned(16))) bf16_t gimg2[2][TY * TX * GRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
     const int m16 = lane & 15, q = lane >> 4;
     const int gq = (lane >> 2) & 3, gp = lane & 3;
-    const int c0 = blockIdx.y * 64, co0 = blockIdx.z * 64 + 32 * wn;
-    const bool do_bias = p.dbias && blockIdx.y == 0 && wm == 0;
+    const int c0 = blockIdx.y * 64, co0 = blockIdx.z * COB + 16 * NJ * wn;
+    // bias gradient = sum of dY over the pixels: every thread sums the four channels it stages (it stages the same channel quad
+    // of every tile), folded through LDS at the end -- four registers instead of the 4 NJ + 4 of an all-ones MFMA operand
+    const bool do_bias = p.dbias && blockIdx.y == 0;          // block-uniform
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
-    bf16x8 ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 acc[9][2], accb[2];
+    f32x4 acc[9][NJ];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int XU = (PATCH * 16 + 511) / 512, GU = TY * TX * 16 / 512;      // 6 and 4 8-byte elements per thread
+    constexpr int GQ = COB / 4;                                                     // 8-byte elements per dY pixel
+    constexpr int XU = (PATCH * 16 + 511) / 512, GU = TY * TX * GQ / 512;      // 6 and 4 (8) 8-byte elements per thread
     const FastDiv d_tx(p.tiles_x), d_ty(p.tiles_y);
     bf16x4 xr[XU], gr[GU];
     // Buffer loads with 32-bit byte offsets: what depends on the thread (patch pixel, channel quad) is computed once, a tile adds
@@ -1780,7 +1787,7 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
     const size_t npix = (size_t)p.B * p.H * p.W;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(npix * p.cs * 2), BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (unsigned)(npix * p.cout * 2), BUF_FLAGS);
-    int xyl[XU], xoff[XU], gyl[GU], goff[GU];          // (ly << 16 | lx) and the thread's byte offset inside a tile at (0, 0)
+    int xyl[XU], xoff[XU];          // (ly << 16 | lx) and the thread's byte offset inside a tile at (0, 0)
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
         const int i = tid + 512 * u, px = i >> 4, c4 = i & 15;
@@ -1788,13 +1795,12 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
         xyl[u] = px < PATCH ? (ly << 16) | lx : 0x7fff7fff;              // past the patch: never inside
         xoff[u] = ((ly * p.W + lx) * p.cs + c0 + 4 * c4) * 2;
     }
-#pragma unroll
-    for (int u = 0; u < GU; ++u) {
-        const int i = tid + 512 * u, px = i >> 4, n4 = i & 15;
-        const int ly = px / TX, lx = px - ly * TX;
-        gyl[u] = (ly << 16) | lx;
-        goff[u] = ((ly * p.W + lx) * p.cout + (int)blockIdx.z * 64 + 4 * n4) * 2;
-    }
+    // dY element u of this thread: pixel tid / GQ + (512 / GQ) u of the tile -- 512 / GQ pixels are GROWS whole tile rows, so
+    // element u sits GROWS u rows below element 0, same column, same channel quad
+    constexpr int GROWS = 512 / GQ / TX;
+    static_assert(512 % GQ == 0 && (512 / GQ) % TX == 0, "dY staging: whole tile rows per element");
+    const int g_ly = (tid / GQ) / TX, g_lx = (tid / GQ) % TX;
+    const int goff0 = ((g_ly * p.W + g_lx) * p.cout + (int)blockIdx.z * COB + 4 * (tid % GQ)) * 2, gstep = GROWS * p.W * p.cout * 2;
     auto issue = [&](int tile) {
         const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x, b = d_ty.div(trow), by = trow - b * p.tiles_y;
         const int x0 = bx * TX, y0 = by * TY;
@@ -1808,9 +1814,9 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int iy = y0 + (gyl[u] >> 16), ix = x0 + (gyl[u] & 0xffff);
+            const int iy = y0 + g_ly + GROWS * u, ix = x0 + g_lx;
             const bool in = iy < p.H && ix < p.W;
-            const unsigned off = in ? (unsigned)(gb + goff[u]) : 0x80000000u;
+            const unsigned off = in ? (unsigned)(gb + goff0 + u * gstep) : 0x80000000u;
             gr[u] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rsg, off, 0, 0));
         }
     };
@@ -1824,8 +1830,12 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int i = tid + 512 * u, px = i >> 4, n4 = i & 15;
-            *reinterpret_cast<bf16x4*>(gimg + px * WRS + 4 * n4) = gr[u];
+            const int i = tid + 512 * u, px = i / GQ, n4 = i % GQ;
+            *reinterpret_cast<bf16x4*>(gimg + px * GRS + 4 * n4) = gr[u];
+            if (do_bias) {          // (pixels outside the image were loaded as zeros)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bsum[k] += (float)gr[u][k];
+            }
         }
     };
 
@@ -1837,7 +1847,7 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
     }
     lds_barrier();
     const int xbase = (4 * q + gq) * WRS + 16 * wm + 4 * gp;
-    const int gbase = (4 * q + gq) * WRS + 32 * wn + 4 * gp;
+    const int gbase = (4 * q + gq) * GRS + 16 * NJ * wn + 4 * gp;
 #pragma unroll 1
     for (; tile < ntiles; tile += p.psplit) {
         if (tile + p.psplit < ntiles) {
@@ -1848,37 +1858,41 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
         const bf16_t* gimg = gimg2[buf];
 #pragma unroll 1
         for (int s = 0; s < TY / 2; ++s) {
-            bf16x8 bv[2];
+            bf16x8 bv[NJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bv[j] = tr_frag(gimg + gbase + (2 * s * TX) * WRS + 16 * j, gimg + gbase + ((2 * s + 1) * TX) * WRS + 16 * j);
+            for (int j = 0; j < NJ; ++j)
+                bv[j] = tr_frag(gimg + gbase + (2 * s * TX) * GRS + 16 * j, gimg + gbase + ((2 * s + 1) * TX) * GRS + 16 * j);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3, dx = t % 3;
                 const bf16x8 av = tr_frag(ximg + xbase + ((2 * s + dy) * (TX + 2) + dx) * WRS,
                                           ximg + xbase + ((2 * s + 1 + dy) * (TX + 2) + dx) * WRS);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[t][j], 0, 0, 0);
-            }
-            if (do_bias) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bv[j], accb[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[t][j], 0, 0, 0);
             }
         }
         lds_barrier();
         buf ^= 1;
     }
-    // D[ci = 16 wm + 4q + i][co = 32 wn + 16j + m16]
+    // D[ci = 16 wm + 4q + i][co = 16 NJ wn + 16j + m16]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 atomicAdd(p.dw + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
-    if (do_bias && q == 0) {
+    if (do_bias) {          // fold the 512 / GQ threads of every channel quad (the tile buffers are free: the loop ended on a barrier)
+        float* red = reinterpret_cast<float*>(&ximg2[0][0]);
+        *reinterpret_cast<float4*>(red + 4 * tid) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+        __syncthreads();
+        if (tid < COB) {
+            const int n4 = tid >> 2, k = tid & 3;
+            float a = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) atomicAdd(p.dbias + co0 + 16 * j + m16, accb[j][0]);
+            for (int r = 0; r < 512 / GQ; ++r) a += red[4 * (n4 + GQ * r) + k];
+            atomicAdd(p.dbias + blockIdx.z * COB + tid, a);
+        }
     }
 }
 
@@ -2547,7 +2561,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
                 static const int narrow = getenv("DNNCA_WGRAD64_NARROW") != nullptr;          // tuning aid
                 if (xh && gh && !narrow && (double)B * w.H * w.W * (w.cs > CO ? w.cs : CO) * 2.0 < 2.0e9) {         // eight waves per block (bf16-stored operands, 32-bit byte offsets)
                     m->set_variant("w8");
-                    LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL(igb::k_igb_wgrad64w, g64, dim3(512), 0, m->stream, w));
+                    LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL(igb::k_igb_wgrad64w<2>, g64, dim3(512), 0, m->stream, w));
                     continue;
                 }
     #define WG64(XH, GH) LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad64<XH, GH>), g64, dim3(256), 0, m->stream, w))
