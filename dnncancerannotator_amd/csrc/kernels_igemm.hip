@@ -67,7 +67,9 @@ struct ConvArgs {
 // (The backward sums of a BatchNorm were tried in the data-gradient epilogue too, twice: the extra read of the BatchNorm's
 // input there costs about what the reduction pass it replaces does -- with the LDS-staged epilogue and one wave per SIMD
 // 2.1 -> 3.2 ms of dgrad against 0.7 ms saved; with this epilogue and two waves per SIMD +0.44 ms of dgrad against 0.63 ms on
-// unet_big, and a net loss on mulmo_unet, where the fold of the per-tile partials also grows.)
+// unet_big, and a net loss on mulmo_unet, where the fold of the per-tile partials also grows.  Round 3, with the self-folding
+// bucket rows of bn_dev.h and the sums taken from the stored bf16 values: 98 -> 192 us per launch -- the 16 two-byte loads per tile
+// row cannot move above the previous row's stores, four exposed round trips per unit.  DESIGN.md section 6.)
 template <int NN, int MODE, int NW = 4>
 __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0, int tile,
                                                float* red) {
