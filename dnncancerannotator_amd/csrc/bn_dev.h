@@ -53,7 +53,7 @@ __device__ __forceinline__ double bn_fold_column(const double* tab, int R, int s
 // persistent kernel finish together, and same-address atomics execute one after the other (~56 ns each: 256 blocks on one counter
 // held the last one up for 14 us) -- so a block draws from one of kBnGroups group counters, and only the last of a group draws
 // from the top counter.  ticket[0]: top, ticket[1 + g]: groups; whoever draws the last ticket of a counter zeroes it.
-constexpr int kBnGroups = 16;
+constexpr int kBnGroups = 32;          // (the ticket array behind the table has 64 slots)
 __device__ __forceinline__ bool bn_last_block(unsigned* ticket, unsigned nblocks, unsigned bid) {
     __shared__ unsigned bn_last;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // this thread's adds have been performed

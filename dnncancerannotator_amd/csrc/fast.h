@@ -50,7 +50,8 @@ bool fast_head_train(Model* m, int B, Op& o, const float* y, const dnnca_loss_cf
 // utils/losses.py:62-67 label_smoothing: Gaussian blur of the labels (false: unsupported filter size / image smaller than the pad)
 bool fast_label_smooth(Model* m, int B, int H, int W, const float* y, float* out, int k, float sigma);
 bool fast_label_stats(Model* m, size_t n, const float* y);
-bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps, Op* pool);   // pool: a 2x2 max-pool of the output that rides in the apply pass
+// pool: a 2x2 max-pool of the output that rides in the apply pass; pool_bn: the BatchNorm of the pooled tensor (its batch statistics ride along too)
+bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps, Op* pool, Op* pool_bn);
 bool fast_bn_pool_fusable(const Model* m, const Op& bn, const Op& pool);
 bool fast_bn_bwd(Model* m, int B, Op& o);
 bool fast_bn_supported(const Model* m, const Op& o);

@@ -687,40 +687,66 @@ __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* _
 
 // BatchNorm apply + the MaxPool2D([2,2], 2) that follows it (components.py:54,59): one thread owns a 4-channel group of a 2 x 2
 // pixel window, writes the four normalised pixels and their maximum -- the pool pass never re-reads the normalised tensor.
+// Grid-stride over the windows (the stride is a multiple of the channel groups: a thread keeps its channel group), so that the
+// batch statistics of the POOLED tensor -- the input of the BatchNorm that follows the pool (components.py:59: pool, BatchNorm) --
+// can ride along: per-thread sums, one LDS fold and 2C bucket adds per block, self-folding (bn_dev.h; f.tab == nullptr: none).
 template <bool YH, bool XH>
 __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const float* __restrict__ x, float* __restrict__ y,
                                                             float* __restrict__ pooled, unsigned* __restrict__ idx, int C, int H,
-                                                            int W, const float* __restrict__ coef) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nwin4) return;
-    const int G = C / 4, cq = (int)(i % G), Wp = W / 2, Hp = H / 2;
-    const size_t wdx = i / G;                          // window index: (b * Hp + yp) * Wp + xp
-    const int xp = (int)(wdx % Wp);
-    const size_t byp = wdx / Wp;                       // b * Hp + yp
-    const size_t b = byp / Hp;
-    const int yp = (int)(byp - b * Hp);
+                                                            int W, const float* __restrict__ coef, BnSelfFold f) {
+    __shared__ float red[256][8];
+    const int G = C / 4, Wp = W / 2, Hp = H / 2;
+    const int cq = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % G);
     const float4 sc = *reinterpret_cast<const float4*>(coef + 4 * cq), sh = *reinterpret_cast<const float4*>(coef + C + 4 * cq);
-    const size_t p00 = ((b * H + 2 * yp) * W + 2 * xp) * C + 4 * cq;
-    float4 mx;
-    unsigned where = 0;          // byte e: window position of channel e's first maximum (the order g_pool_bwd searches in)
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwin4; i += (size_t)gridDim.x * 256) {
+        const size_t wdx = i / G;                          // window index: (b * Hp + yp) * Wp + xp
+        const int xp = (int)(wdx % Wp);
+        const size_t byp = wdx / Wp;                       // b * Hp + yp
+        const size_t b = byp / Hp;
+        const int yp = (int)(byp - b * Hp);
+        const size_t p00 = ((b * H + 2 * yp) * W + 2 * xp) * C + 4 * cq;
+        float4 v4[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const size_t o = p00 + ((size_t)(k >> 1) * W + (k & 1)) * C;
-        const float4 v = ld4<XH>(x, o);
-        float4 r;
-        r.x = fmaf(v.x, sc.x, sh.x); r.y = fmaf(v.y, sc.y, sh.y); r.z = fmaf(v.z, sc.z, sh.z); r.w = fmaf(v.w, sc.w, sh.w);
-        if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + o) = to_bf16x4(r);
-        else *reinterpret_cast<float4*>(y + o) = r;
-        if (k == 0) mx = r;
-        else {
-            if (r.x > mx.x) { mx.x = r.x; where = (where & 0xffffff00u) | (unsigned)k; }
-            if (r.y > mx.y) { mx.y = r.y; where = (where & 0xffff00ffu) | ((unsigned)k << 8); }
-            if (r.z > mx.z) { mx.z = r.z; where = (where & 0xff00ffffu) | ((unsigned)k << 16); }
-            if (r.w > mx.w) { mx.w = r.w; where = (where & 0x00ffffffu) | ((unsigned)k << 24); }
+        for (int k = 0; k < 4; ++k) v4[k] = ld4<XH>(x, p00 + ((size_t)(k >> 1) * W + (k & 1)) * C);
+        float4 mx;
+        unsigned where = 0;          // byte e: window position of channel e's first maximum (the order g_pool_bwd searches in)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t o = p00 + ((size_t)(k >> 1) * W + (k & 1)) * C;
+            const float4 v = v4[k];
+            float4 r;
+            r.x = fmaf(v.x, sc.x, sh.x); r.y = fmaf(v.y, sc.y, sh.y); r.z = fmaf(v.z, sc.z, sh.z); r.w = fmaf(v.w, sc.w, sh.w);
+            if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + o) = to_bf16x4(r);
+            else *reinterpret_cast<float4*>(y + o) = r;
+            if (k == 0) mx = r;
+            else {
+                if (r.x > mx.x) { mx.x = r.x; where = (where & 0xffffff00u) | (unsigned)k; }
+                if (r.y > mx.y) { mx.y = r.y; where = (where & 0xffff00ffu) | ((unsigned)k << 8); }
+                if (r.z > mx.z) { mx.z = r.z; where = (where & 0xff00ffffu) | ((unsigned)k << 16); }
+                if (r.w > mx.w) { mx.w = r.w; where = (where & 0x00ffffffu) | ((unsigned)k << 24); }
+            }
         }
+        *reinterpret_cast<float4*>(pooled + wdx * C + 4 * cq) = mx;
+        if (idx) idx[i] = where;
+        bs.x += mx.x; bs.y += mx.y; bs.z += mx.z; bs.w += mx.w;
+        bq.x = fmaf(mx.x, mx.x, bq.x); bq.y = fmaf(mx.y, mx.y, bq.y); bq.z = fmaf(mx.z, mx.z, bq.z); bq.w = fmaf(mx.w, mx.w, bq.w);
     }
-    *reinterpret_cast<float4*>(pooled + wdx * C + 4 * cq) = mx;
-    if (idx) idx[i] = where;
+    if (!f.tab) return;
+    red[threadIdx.x][0] = bs.x; red[threadIdx.x][1] = bs.y; red[threadIdx.x][2] = bs.z; red[threadIdx.x][3] = bs.w;
+    red[threadIdx.x][4] = bq.x; red[threadIdx.x][5] = bq.y; red[threadIdx.x][6] = bq.z; red[threadIdx.x][7] = bq.w;
+    __syncthreads();
+    // thread t of the block handles channel group (blockIdx * 256 + t) % G: the groups of lanes t, t + G, ... coincide when G | 256
+    const int g0 = (int)(((size_t)blockIdx.x * 256) % G), PL = 256 / G;
+    double* row = bn_bucket(f, (int)blockIdx.x);
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        const int c = o % C, which = o / C;
+        const int lane0 = ((c >> 2) - g0 + G) % G;          // first thread of the block that owns channel group c / 4
+        float a = 0.f;
+        for (int l = 0; l < PL; ++l) a += red[lane0 + l * G][4 * which + (c & 3)];
+        atomicAdd(row + o, (double)a);
+    }
+    bn_self_fold(f, gridDim.x, blockIdx.x);
 }
 
 // MaxPool2D([2,2], 2) backward by the recorded positions: din = (acc ? din : 0) + route(dout); one thread = a 4-channel group of a window
@@ -848,7 +874,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
 }
 
 static bool bn_table(Model* m) {          // arrives zeroed, stays zeroed between uses
-    return m->bn_tab || m->alloc((void**)&m->bn_tab, (size_t)(Model::kBnTab + 16) * 8) == DNNCA_OK;          // + the ticket counters
+    return m->bn_tab || m->alloc((void**)&m->bn_tab, (size_t)(Model::kBnTab + 32) * 8) == DNNCA_OK;          // + the ticket counters
 }
 
 bool bn_self_fold_args(Model* m, Op& bn, int B, BnSelfFold* f) {
@@ -889,7 +915,7 @@ bool fast_bn_pool_fusable(const Model* m, const Op& bn, const Op& pool) {
            pool.out.d.ps == pool.out.d.C && bn.out.d.H % 2 == 0 && bn.out.d.W % 2 == 0;
 }
 
-bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps, Op* pool) {
+bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps, Op* pool, Op* pool_bn) {
     if (!bn_fast_ok(o.inA.d) || o.out.d.ps % 4) return false;
     const int C = o.inA.d.C;
     const size_t npix = (size_t)B * o.inA.d.H * o.inA.d.W;
@@ -922,13 +948,20 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
             if (m->alloc(&ix, (size_t)m->desc.max_batch * pool->out.d.H * pool->out.d.W * C) == DNNCA_OK) pool->pool_idx = (unsigned char*)ix;
         }
         pool->pool_idx_valid = m->dry || pool->pool_idx != nullptr;     // the dry run lists the launches of the real one
-        const dim3 grid((unsigned)((n4 / 4 + 255) / 256));
+        // grid-stride: at most 1024 blocks (the statistics of the pooled tensor cost one LDS fold and one ticket per block: measured
+        // per launch on unet_big 37.7 / 41.0 / 45.9 / 54.8 us with 1024 / 2048 / 4096 / 8192 blocks); the stride 256 x blocks is a
+        // multiple of the channel groups (C / 4 divides 256: bn_fast_ok)
+        static const unsigned max_blocks = getenv("DNNCA_POOL_BLOCKS") ? (unsigned)atoi(getenv("DNNCA_POOL_BLOCKS")) : 1024u;      // tuning aid
+        const size_t need = (n4 / 4 + 255) / 256;
+        const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
         unsigned* ix = reinterpret_cast<unsigned*>(pool->pool_idx);
+        BnSelfFold pf{};          // batch statistics of the pooled tensor for the BatchNorm behind the pool
+        if (pool_bn && training && !getenv("DNNCA_NO_BN_FUSION") && !getenv("DNNCA_NO_POOL_STATS")) (void)bn_self_fold_args(m, *pool_bn, B, &pf);
         // bytes: x in (f32 or bf16), y out (f32 or bf16), pooled out (a quarter, f32)
         const double pb = tb * ((o.inA.d.h ? 0.5 : 1.0) + (o.out.d.h ? 0.5 : 1.0) + 0.25);
 #define BNPOOL(YHv, XHv) LAUNCH(m, "bn_apply_pool", pb, tb / 2,                                                              \
         hipLaunchKernelGGL((k_bn_apply_pool_fast<YHv, XHv>), grid, dim3(256), 0, m->stream, n4 / 4, o.inA.d.p, o.out.d.p,    \
-                           pool->out.d.p, ix, C, o.inA.d.H, o.inA.d.W, o.coef))
+                           pool->out.d.p, ix, C, o.inA.d.H, o.inA.d.W, o.coef, pf))
         if (o.out.d.h) { if (o.inA.d.h) BNPOOL(true, true); else BNPOOL(true, false); }
         else { if (o.inA.d.h) BNPOOL(false, true); else BNPOOL(false, false); }
 #undef BNPOOL

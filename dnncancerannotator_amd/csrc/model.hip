@@ -511,7 +511,9 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 double n = (double)B * o.inA.d.H * o.inA.d.W;
                 double tb = 4.0 * nelem(B, o.inA.d);
                 Op* bn_pool = (!generic && oi + 1 < ops.size() && fast_bn_pool_fusable(this, o, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
-                if (!generic && fast_bn_fwd(this, B, o, training, kBnMomentum, kBnEps, bn_pool)) {
+                Op* pool_bn = (bn_pool && training && oi + 2 < ops.size() && ops[oi + 2].type == OP_BN &&
+                               ops[oi + 2].inA.d.p == bn_pool->out.d.p && fast_bn_supported(this, ops[oi + 2])) ? &ops[oi + 2] : nullptr;
+                if (!generic && fast_bn_fwd(this, B, o, training, kBnMomentum, kBnEps, bn_pool, pool_bn)) {
                     if (bn_pool) pool_done = bn_pool;
                     break;
                 }
