@@ -64,6 +64,8 @@ int ig_begin_backward(Model* m);
 void ig_release(Model* m);
 bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);   // bn_next: BatchNorm of the output whose statistics may ride in the epilogue
 bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);
+// will this conv's forward and weight-gradient launches (batch B) be the kernels that can normalise a BatchNorm's input while staging it?
+bool ig_norm_on_load_ok(const Model* m, int B, const Op& o);
 struct BnSelfFold;
 // batch statistics of BatchNorm `bn` folded by the kernel that produces its input (bn_dev.h): fills *f and marks the statistics as
 // taken care of (Op::fused_stats_rows); false: not available (the BatchNorm then runs its own reduction pass)

@@ -51,6 +51,10 @@ struct ConvArgs {
     // forward: batch statistics of the BatchNorm behind this conv ride in the epilogue of the persistent kernels, which fold them
     // themselves (bn_dev.h; bnf.tab == nullptr: none)
     BnSelfFold bnf;
+    // forward, k_ig_conv3: source k is the INPUT of a BatchNorm whose apply pass was elided; its scale / shift (norm[k][c],
+    // norm[k][c_srck + c]: the BatchNorm's coefficient table) are applied while the patch goes to LDS -- pixels outside the image
+    // stay zero, as the padding of the normalised tensor would be (nullptr: the source is used as it is)
+    const float* norm[2];
     int src_half;            // the sources are stored as bf16 (View::h; k_igb_conv3 only)
     int dst_half;            // forward, persistent kernels: dst[0] is stored as bf16 (the input of a BatchNorm, ig_plan_half)
     int dsth[2];             // data gradient, persistent kernels: dst[k] is stored as bf16 (the gradient arriving at a BatchNorm)
@@ -306,6 +310,7 @@ struct WgArgs {
     // same-address atomics execute one after the other (~56 ns each): when many blocks share a small gradient, block b adds
     // into copy b % nbuckets of it (dw / dbias then point at copy 0, copies bucket_stride floats apart; k_wg_fold sums them)
     int nbuckets, bucket_stride;
+    const float* norm;       // k_ig_wgrad2: x is the input of a BatchNorm whose apply pass was elided (scale norm[c], shift norm[cs + c]); nullptr: none
 };
 
 // grid: x = pixel split, y = input-channel chunk (16), z = output-channel tile (16*NN)
@@ -436,7 +441,17 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
 
     // staging geometry: X element u = patch pixel (tid + 256u) / XQ, float4 (tid + 256u) % XQ; dY likewise with GQ
     wg_u32x4 xr[XU], gr[GU];
+    // normalise-on-load (WgArgs::norm): the thread stages the same channel quad of every element (NT is a multiple of XQ)
+    static_assert(NT % XQ == 0, "one channel quad per thread");
+    const bool norm_on = p.norm != nullptr;
+    float4 n_sc = make_float4(1.f, 1.f, 1.f, 1.f), n_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (norm_on) {
+        n_sc = *reinterpret_cast<const float4*>(p.norm + c0 + 4 * (tid % XQ));
+        n_sh = *reinterpret_cast<const float4*>(p.norm + p.cs + c0 + 4 * (tid % XQ));
+    }
+    unsigned x_in = 0u;                        // bit u: element u of the tile in registers lies inside the image
     auto issue = [&](int tile) {               // tile >= ntiles: stage nothing (every offset out of range)
+        x_in = 0u;
         const unsigned oob = tile < ntiles ? 0u : WG_OOB;
         tile = tile < ntiles ? tile : 0;
         const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x, b = d_ty.div(trow), by = trow - b * tiles_y;
@@ -449,6 +464,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
             const bool ok = px < PPATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const unsigned off = (ok ? (unsigned)(((((b * p.H + iy) * p.W + ix) * p.cs) + c0 + 4 * c4) * 4) : WG_OOB) | oob;
             xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+            x_in |= (ok && !oob) ? (1u << u) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
@@ -465,6 +481,13 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
         for (int u = 0; u < XU; ++u) {
             const int i = tid + NT * u, px = i / XQ, c4 = i % XQ;
             // lanes past the patch (last element only) write into the 16-float dump row behind it
+            if (norm_on) {          // block-uniform
+                f32x4 f = __builtin_bit_cast(f32x4, xr[u]);
+                const bool in = (x_in >> u) & 1u;
+                f[0] = in ? fmaf(f[0], n_sc.x, n_sh.x) : 0.f; f[1] = in ? fmaf(f[1], n_sc.y, n_sh.y) : 0.f;
+                f[2] = in ? fmaf(f[2], n_sc.z, n_sh.z) : 0.f; f[3] = in ? fmaf(f[3], n_sc.w, n_sh.w) : 0.f;
+                xr[u] = __builtin_bit_cast(wg_u32x4, f);
+            }
             *reinterpret_cast<wg_u32x4*>(x_lds + (px < PPATCH ? px * XS + 4 * c4 : PPATCH * XS + 4 * (c4 & 3))) = xr[u];
         }
 #pragma unroll
@@ -671,11 +694,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
         }
         return st;
     };
+    // normalise-on-load (MODE 0, ConvArgs::norm): the item in registers carries its thread's scale / shift quad and an
+    // inside-the-image bit per element (`cur`); the item being issued builds the next set (`nxt`)
+    const bool norm_any = MODE == 0 && (p.norm[0] != nullptr || p.norm[1] != nullptr);          // block-uniform
+    float4 n_sc_cur = make_float4(1.f, 1.f, 1.f, 1.f), n_sh_cur = make_float4(0.f, 0.f, 0.f, 0.f), n_sc_nxt = n_sc_cur, n_sh_nxt = n_sh_cur;
+    unsigned a_in_cur = 0u, a_in_nxt = 0u;
+    auto stage_coef = [&](const Stage& st, float4& sc, float4& sh) {
+        sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 0) {
+            const float* nt = p.norm[st.cc >= p.c_src0 ? 1 : 0];          // uniform
+            if (nt) {
+                sc = *reinterpret_cast<const float4*>(nt + st.c0 + 4 * c4);
+                sh = *reinterpret_cast<const float4*>(nt + st.cs + st.c0 + 4 * c4);
+            }
+        }
+    };
     auto issue_a = [&](const Stage& st, int v) {
         const int iy = st.y0 - 1 + a_ly[v], ix = st.x0 - 1 + a_lx[v];
         const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const unsigned off = (ok ? (unsigned)(((((st.b * p.H + iy) * p.W + ix) * st.cs) + st.c0 + 4 * c4) * 4) : WG_OOB) | st.oob;
         ar[v] = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
+        if (MODE == 0) a_in_nxt |= ok ? (1u << v) : 0u;
     };
     auto issue_b = [&](const Stage& st, int v) {
         const int i = tid + NT * v, n4 = i % (4 * NN), r = i / (4 * NN);
@@ -685,6 +725,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
     };
     auto commit_a = [&](float* buf, int v) {
         const int px = (tid >> 2) + (NT / 4) * v;
+        if (norm_any) {
+            f32x4 f = __builtin_bit_cast(f32x4, ar[v]);
+            const bool in = (a_in_cur >> v) & 1u;
+            f[0] = in ? fmaf(f[0], n_sc_cur.x, n_sh_cur.x) : 0.f; f[1] = in ? fmaf(f[1], n_sc_cur.y, n_sh_cur.y) : 0.f;
+            f[2] = in ? fmaf(f[2], n_sc_cur.z, n_sh_cur.z) : 0.f; f[3] = in ? fmaf(f[3], n_sc_cur.w, n_sh_cur.w) : 0.f;
+            ar[v] = __builtin_bit_cast(wg_u32x4, f);
+        }
         *reinterpret_cast<wg_u32x4*>(buf + (px < PATCHX ? px * F3AS : ABUF + BBUF) + 4 * c4) = ar[v];     // idle lanes: dump row
     };
     auto commit_b = [&](float* buf, int v) {
@@ -695,19 +742,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
     f32x4 acc[4][NN];
     {
         const Stage s0 = next_stage();
+        if (norm_any) stage_coef(s0, n_sc_cur, n_sh_cur);
 #pragma unroll
         for (int v = 0; v < AU; ++v) issue_a(s0, v);
 #pragma unroll
         for (int v = 0; v < BU; ++v) issue_b(s0, v);
+        a_in_cur = a_in_nxt;
+        a_in_nxt = 0u;
 #pragma unroll
         for (int v = 0; v < AU; ++v) commit_a(lds, v);
 #pragma unroll
         for (int v = 0; v < BU; ++v) commit_b(lds, v);
         const Stage s1 = next_stage();
+        if (norm_any) stage_coef(s1, n_sc_cur, n_sh_cur);
 #pragma unroll
         for (int v = 0; v < AU; ++v) issue_a(s1, v);
 #pragma unroll
         for (int v = 0; v < BU; ++v) issue_b(s1, v);
+        a_in_cur = a_in_nxt;
+        a_in_nxt = 0u;
     }
     lds_barrier();
     int it = 0;          // units outside, K chunks inside (see igb::k_igb_conv3)
@@ -722,6 +775,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
         float* buf = lds + (it & 1) * BUF;
         float* other = lds + ((it & 1) ^ 1) * BUF;
         const Stage nx = next_stage();           // item it + 2
+        if (norm_any) stage_coef(nx, n_sc_nxt, n_sh_nxt);          // used by the NEXT item's commits: the loads have a whole item to land
         const float* a_lds = buf + ((4 * wave) * (F3T + 2) + m16) * F3AS + q;
         const float* b_lds = buf + ABUF + q * BS + m16;
         // step s = (dx = s / 4, K-step k4 = s % 4): 6 A words (rows 0..5) + 3 x NN B words (dy = 0..2)
@@ -751,6 +805,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
 #pragma unroll
                     for (int j = 0; j < NN; ++j)
                         acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s & 1][r + dy], fb[s & 1][dy][j], acc[r][j], 0, 0, 0);
+        }
+        if (MODE == 0) {          // the registers now hold item it + 2
+            n_sc_cur = n_sc_nxt; n_sh_cur = n_sh_nxt;
+            a_in_cur = a_in_nxt;
+            a_in_nxt = 0u;
         }
         lds_barrier();
     }
@@ -2474,10 +2533,43 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
     else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((igb::k_igb_conv<2, MODE>), grid, dim3(256), 0, m->stream, a, w16));
 }
 
+// the launch condition of k_ig_wgrad2 (second-generation fp32 weight gradient) for a source of cs channels
+static bool wgrad2_ok(const Model* m, const Op& o, int B, int cs) {
+    const int CO = o.out.d.C;
+    return !use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (cs > CO ? cs : CO) * 4.0 < 2.0e9 && !getenv("DNNCA_WGRAD1");
+}
+
+static ig::ConvArgs conv_fwd_geometry(int B, const Op& o) {
+    ig::ConvArgs a{};
+    a.c_src0 = o.inA.d.C; a.c_src1 = o.inB.d.C;
+    a.n_dst0 = o.out.d.C; a.n_dst1 = 0;
+    a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
+    return a;
+}
+
+bool ig_norm_on_load_ok(const Model* m, int B, const Op& o) {
+    static const bool off = getenv("DNNCA_NO_NORM_ON_LOAD") != nullptr;
+    if (off || m->desc.dtype != DNNCA_F32 || !ig_conv_supported(m, o) || use_bf16(m, o)) return false;
+    return conv3_path(conv_fwd_geometry(B, o), o.out.d.C, false) && wgrad2_ok(m, o, B, o.inA.d.C) && (!o.inB.d.C || wgrad2_ok(m, o, B, o.inB.d.C));
+}
+
+// source k of conv o for the kernels that normalise on load: the BatchNorm's input + coefficient table when its apply pass was elided
+static const float* conv_source(Model* m, const Op& o, int k, const float** norm) {
+    const View& v = k ? o.inB.d : o.inA.d;
+    *norm = nullptr;
+    if (o.src_bn[k] >= 0 && m->ops[o.src_bn[k]].elided) {
+        const Op& bn = m->ops[o.src_bn[k]];
+        *norm = bn.coef;
+        return bn.inA.d.p;
+    }
+    return v.p;
+}
+
 bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next) {
     if (!ig_conv_supported(m, o)) return false;
     ig::ConvArgs a{};
-    a.src[0] = o.inA.d.p; a.src[1] = o.inB.d.p;
+    a.src[0] = conv_source(m, o, 0, &a.norm[0]);
+    a.src[1] = o.inB.d.C ? conv_source(m, o, 1, &a.norm[1]) : o.inB.d.p;
     a.c_src0 = o.inA.d.C; a.c_src1 = o.inB.d.C;
     a.w = m->p + o.w_off;
     a.bias = m->p + o.b_off;
@@ -2513,9 +2605,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
     // small gradients shared by many blocks go through bucket copies (see WgArgs::nbuckets); fp32 second-generation kernel only
     const int n_w = 9 * (CA + CB) * CO;
     bool bucketed = false;
-    auto wgrad2_path = [&](int cs) {        // the launch condition of k_ig_wgrad2 below
-        return !use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (cs > CO ? cs : CO) * 4.0 < 2.0e9 && !getenv("DNNCA_WGRAD1");
-    };
+    auto wgrad2_path = [&](int cs) { return wgrad2_ok(m, o, B, cs); };        // the launch condition of k_ig_wgrad2 below
     auto wgrad2_psplit = [&](int cs) {
         const int mw = cs % 64 == 0 ? 4 : (cs % 32 == 0 ? 2 : 1), nn = pick_nn(CO);
         const int combos = (cs / (16 * mw)) * (CO / (16 * nn));
@@ -2532,7 +2622,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         const bool side = m->wg_side_begin();
         for (int s = 0; s < (CB ? 2 : 1); ++s) {
             ig::WgArgs w{};
-            w.x = s == 0 ? o.inA.d.p : o.inB.d.p;
+            w.x = conv_source(m, o, s, &w.norm);
             w.dz = o.out.g.p;
             w.dw = bucketed ? pl.wg_slabs : m->g + o.w_off;
             w.dbias = s == 0 ? (bucketed ? pl.wg_slabs + n_w : m->g + o.b_off) : nullptr;

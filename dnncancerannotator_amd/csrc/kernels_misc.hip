@@ -941,6 +941,7 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
                g_bn_finalize(m->stream, C, (double)npix, o.ws, m->p + o.w_off, m->p + o.b_off, m->state + o.mm_off,
                              m->state + o.mv_off, o.coef, 0, momentum, eps));
     }
+    if (o.elided) return true;          // the readers apply scale / shift themselves (Op::elided): coefficients are all they need
     const size_t n4 = npix * (C / 4);
     if (pool) {          // the caller checked fast_bn_pool_fusable(o, *pool)
         if (!pool->pool_idx && !m->dry) {

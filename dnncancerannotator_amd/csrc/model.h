@@ -38,6 +38,13 @@ struct Op {
     // BN batch statistics that rode in the producing conv's epilogue this step: rows of float partials waiting in the
     // model's partials table (0: none)
     int fused_stats_rows = 0;
+    // BatchNorm apply elided (f32 dense path): when every reader of a BatchNorm's output is a 3x3 conv that normalises while it
+    // stages its operands (k_ig_conv3 forward, k_ig_wgrad2), the apply pass and the normalised tensor are skipped for the step
+    // (`elided`, decided by the forward pass, valid until the next one); the convs read the BatchNorm's INPUT and its coefficients.
+    // src_bn[k]: the BatchNorm op that produces conv input k (-1: none); out_readers: the ops that read this op's output tensor
+    bool elided = false;
+    int src_bn[2] = {-1, -1};
+    std::vector<int> out_readers;
     // pool: position (0..3, row-major in the 2x2 window) of each output's first maximum, written by the fused BN-apply + pool
     // pass of this step; the backward pass routes by it instead of re-reading the input and output tensors
     unsigned char* pool_idx = nullptr;

@@ -376,6 +376,20 @@ int Model::build() {
         }
     }
 
+    // who reads a BatchNorm's output, and which BatchNorm feeds a conv input (exact tensors only: channel slices do not count)
+    for (int b = 0; b < (int)ops.size(); ++b) {
+        if (ops[b].type != OP_BN) continue;
+        const View& y = ops[b].out.d;
+        for (int i = 0; i < (int)ops.size(); ++i) {
+            Op& o = ops[i];
+            const bool a = o.inA.d.p == y.p && o.inA.d.C == y.C && o.inA.d.ps == y.ps;
+            const bool bb = o.type == OP_CONV && o.inB.d.C && o.inB.d.p == y.p && o.inB.d.C == y.C && o.inB.d.ps == y.ps;
+            const bool overlap = !a && !bb && ((o.inA.d.p >= y.p && o.inA.d.p < y.p + y.ps) || (o.type == OP_CONV && o.inB.d.C && o.inB.d.p >= y.p && o.inB.d.p < y.p + y.ps));
+            if (a || bb || overlap) ops[b].out_readers.push_back(overlap ? -1 : i);          // -1: a reader this analysis does not understand
+            if (o.type == OP_CONV && a) o.src_bn[0] = b;
+            if (bb) o.src_bn[1] = b;
+        }
+    }
     fast_plan_masks(this);
     DN_TRY(ig_plan_half(this));
 
@@ -511,6 +525,13 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 double n = (double)B * o.inA.d.H * o.inA.d.W;
                 double tb = 4.0 * nelem(B, o.inA.d);
                 Op* bn_pool = (!generic && oi + 1 < ops.size() && fast_bn_pool_fusable(this, o, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
+                // every reader a conv that normalises while it stages its operands: no apply pass, no normalised tensor
+                o.elided = false;
+                if (!generic && !bn_pool && !o.out_readers.empty() && fast_bn_supported(this, o)) {
+                    bool all = true;
+                    for (int r : o.out_readers) all = all && r >= 0 && ops[r].type == OP_CONV && ig_norm_on_load_ok(this, B, ops[r]);
+                    o.elided = all;
+                }
                 Op* pool_bn = (bn_pool && training && oi + 2 < ops.size() && ops[oi + 2].type == OP_BN &&
                                ops[oi + 2].inA.d.p == bn_pool->out.d.p && fast_bn_supported(this, ops[oi + 2])) ? &ops[oi + 2] : nullptr;
                 if (!generic && fast_bn_fwd(this, B, o, training, kBnMomentum, kBnEps, bn_pool, pool_bn)) {
