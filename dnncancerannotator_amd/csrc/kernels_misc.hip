@@ -690,7 +690,9 @@ __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* _
 // Grid-stride over the windows (the stride is a multiple of the channel groups: a thread keeps its channel group), so that the
 // batch statistics of the POOLED tensor -- the input of the BatchNorm that follows the pool (components.py:59: pool, BatchNorm) --
 // can ride along: per-thread sums, one LDS fold and 2C bucket adds per block, self-folding (bn_dev.h; f.tab == nullptr: none).
-template <bool YH, bool XH>
+// WY = false: nobody but the pool reads the normalised tensor (mulmo_unet: the encoders whose skips the decoder does not take,
+// unet.py:183-187 reference_index) -- it is not written.
+template <bool YH, bool XH, bool WY>
 __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const float* __restrict__ x, float* __restrict__ y,
                                                             float* __restrict__ pooled, unsigned* __restrict__ idx, int C, int H,
                                                             int W, const float* __restrict__ coef, BnSelfFold f) {
@@ -717,8 +719,10 @@ __global__ __launch_bounds__(256) void k_bn_apply_pool_fast(size_t nwin4, const 
             const float4 v = v4[k];
             float4 r;
             r.x = fmaf(v.x, sc.x, sh.x); r.y = fmaf(v.y, sc.y, sh.y); r.z = fmaf(v.z, sc.z, sh.z); r.w = fmaf(v.w, sc.w, sh.w);
-            if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + o) = to_bf16x4(r);
-            else *reinterpret_cast<float4*>(y + o) = r;
+            if (WY) {
+                if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + o) = to_bf16x4(r);
+                else *reinterpret_cast<float4*>(y + o) = r;
+            }
             if (k == 0) mx = r;
             else {
                 if (r.x > mx.x) { mx.x = r.x; where = (where & 0xffffff00u) | (unsigned)k; }
@@ -958,13 +962,20 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
         unsigned* ix = reinterpret_cast<unsigned*>(pool->pool_idx);
         BnSelfFold pf{};          // batch statistics of the pooled tensor for the BatchNorm behind the pool
         if (pool_bn && training && !getenv("DNNCA_NO_BN_FUSION") && !getenv("DNNCA_NO_POOL_STATS")) (void)bn_self_fold_args(m, *pool_bn, B, &pf);
-        // bytes: x in (f32 or bf16), y out (f32 or bf16), pooled out (a quarter, f32)
-        const double pb = tb * ((o.inA.d.h ? 0.5 : 1.0) + (o.out.d.h ? 0.5 : 1.0) + 0.25);
-#define BNPOOL(YHv, XHv) LAUNCH(m, "bn_apply_pool", pb, tb / 2,                                                              \
-        hipLaunchKernelGGL((k_bn_apply_pool_fast<YHv, XHv>), grid, dim3(256), 0, m->stream, n4 / 4, o.inA.d.p, o.out.d.p,    \
+        // does anybody but the pool read the normalised tensor?  (out_readers: model.hip; -1 = a reader it does not understand)
+        bool write_y = o.out_readers.empty();
+        for (int r : o.out_readers) write_y = write_y || r < 0 || &m->ops[r] != pool;
+        // (the pool's backward must be the one that routes by the recorded positions: any other re-reads the normalised tensor)
+        write_y = write_y || !pool->pool_idx_valid || !dense(pool->inA.g) || !dense(pool->out.g) || pool->maskA;
+        // bytes: x in (f32 or bf16), y out (f32 or bf16; not when only the pool reads it), pooled out (a quarter, f32)
+        const double pb = tb * ((o.inA.d.h ? 0.5 : 1.0) + (write_y ? (o.out.d.h ? 0.5 : 1.0) : 0.0) + 0.25);
+#define BNPOOL(YHv, XHv, WYv) LAUNCH(m, "bn_apply_pool", pb, tb / 2,                                                         \
+        hipLaunchKernelGGL((k_bn_apply_pool_fast<YHv, XHv, WYv>), grid, dim3(256), 0, m->stream, n4 / 4, o.inA.d.p, o.out.d.p, \
                            pool->out.d.p, ix, C, o.inA.d.H, o.inA.d.W, o.coef, pf))
-        if (o.out.d.h) { if (o.inA.d.h) BNPOOL(true, true); else BNPOOL(true, false); }
-        else { if (o.inA.d.h) BNPOOL(false, true); else BNPOOL(false, false); }
+        m->set_variant("y%d", (int)write_y);
+        if (!write_y) { if (o.inA.d.h) BNPOOL(false, true, false); else BNPOOL(false, false, false); }
+        else if (o.out.d.h) { if (o.inA.d.h) BNPOOL(true, true, true); else BNPOOL(true, false, true); }
+        else { if (o.inA.d.h) BNPOOL(false, true, true); else BNPOOL(false, false, true); }
 #undef BNPOOL
         return true;
     }
