@@ -277,7 +277,7 @@ def test_dense_configs_at_real_widths_against_oracle(gpu, arch, C, opts, B, size
 
 def test_batchnorm_reductions_fold_themselves_repeatably(gpu):
     """The BatchNorm reductions add their partial sums to a small table with double atomics and the last block of the same launch
-    folds it and leaves it zeroed (csrc/bn_dev.h).  Ten steps at learning rate 0 on one model: every step finds the table zeroed (a
+    folds it and leaves it zeroed (csrc/bn_dev.h).  A hundred steps at learning rate 0 on one model: every step finds the table zeroed (a
     leftover would show up in the very next BatchNorm's statistics), so every step reproduces the first one's loss, BatchNorm
     gradients and batch statistics -- the double sums of float partials do not depend on the order the blocks arrive in (what is
     allowed to move is the float32 weight-gradient atomics of the convs)."""
@@ -293,7 +293,7 @@ def test_batchnorm_reductions_fold_themselves_repeatably(gpu):
         s0 = m.get_state()
         cfg = m.loss_cfg(weight_mul=3.0)
         first = None
-        for step in range(10):
+        for step in range(100):
             m.set_state(s0)
             out = m.train_step(x, y, 0.0, cfg)
             g, st = m.get_grads().astype(np.float64), m.get_state().astype(np.float64)
