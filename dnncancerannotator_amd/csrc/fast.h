@@ -54,6 +54,7 @@ bool fast_label_stats(Model* m, size_t n, const float* y);
 bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float eps, Op* pool, Op* pool_bn);
 bool fast_bn_pool_fusable(const Model* m, const Op& bn, const Op& pool);
 bool fast_bn_bwd(Model* m, int B, Op& o);
+bool fast_pool_into_bn(Model* m, Op& pool, Op& bn);      // the pool's backward rides in the backward passes of the BatchNorm in front of it
 bool fast_bn_supported(const Model* m, const Op& o);
 void fast_plan_masks(Model* m);
 // implicit-GEMM MFMA path for channel counts that are multiples of 16 (kernels_igemm.hip)

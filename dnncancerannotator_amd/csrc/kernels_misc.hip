@@ -780,16 +780,45 @@ __global__ __launch_bounds__(256) void k_pool2_bwd_idx(size_t nwin4, const float
     }
 }
 
+// The gradient that reaches a BatchNorm through the 2x2 max-pool behind it (components.py:54,59: ... BatchNorm, pool), routed by the
+// recorded window positions while the BatchNorm's two backward passes read their operands: the pool's own backward pass
+// (k_pool2_bwd_idx: a read-modify-write of the whole dy, or its first write) is not run, and where the pool is the only reader
+// of the BatchNorm's output dy is never materialised.  PG = 1: dy is the routed gradient alone; PG = 2: dy holds the skip
+// connection's gradient, the routed one is added.  With bf16-stored gradients the sum is rounded to bf16 as the pool pass stored it.
+struct PoolGrad {
+    const float* dpool;      // gradient of the pooled tensor, dense NHWC [B][H/2][W/2][C], f32
+    const unsigned* idx;     // one byte per pooled element: window position (0..3) of the maximum
+    int H, W;                // of the BatchNorm's tensor
+    unsigned mW, mH;         // floor(2^32 / W) + 1, floor(2^32 / H) + 1: pixel index -> (b, y, x) without divisions (pixels x W < 2^32)
+};
+
+template <int PG, bool GH>
+__device__ __forceinline__ float4 with_pool_grad(float4 d, const PoolGrad& g, unsigned pix, int cq, int G) {
+    if (PG == 0) return d;
+    const unsigned t = __umulhi(pix, g.mW), x = pix - t * (unsigned)g.W;          // t = b * H + y
+    const unsigned b = __umulhi(t, g.mH), y = t - b * (unsigned)g.H;
+    const size_t w4 = ((size_t)(b * (unsigned)(g.H >> 1) + (y >> 1)) * (unsigned)(g.W >> 1) + (x >> 1)) * G + cq;
+    const unsigned k = ((y & 1u) << 1) | (x & 1u), where = g.idx[w4];
+    const float4 v = reinterpret_cast<const float4*>(g.dpool)[w4];
+    if (PG == 1) d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((where & 0xffu) == k) d.x += v.x;
+    if (((where >> 8) & 0xffu) == k) d.y += v.y;
+    if (((where >> 16) & 0xffu) == k) d.z += v.z;
+    if ((where >> 24) == k) d.w += v.w;
+    if (GH) { d.x = (float)(hbf16)d.x; d.y = (float)(hbf16)d.y; d.z = (float)(hbf16)d.z; d.w = (float)(hbf16)d.w; }
+    return d;
+}
+
 // Sums of one BatchNorm backward (dgamma = sum dy * xhat, dbeta = sum dy) -- and their fold: every block adds its 2C partial sums
 // to one of R bucket rows (double atomics, bn_dev.h; a row meets gridDim / R blocks), takes a ticket, and the block that draws the
 // last one folds the R rows, adds the result to dgamma / dbeta and leaves rows and ticket zeroed for the next BatchNorm.
 // No fold launch between this pass and the apply pass (it was a 9 us kernel of 8 .. 128 blocks plus a dependent launch, 24 / 48
 // times per step of the dense configurations).
-template <bool XH, bool GH>      // XH / GH: x / dy is stored as bf16
+template <bool XH, bool GH, int PG>      // XH / GH: x / dy is stored as bf16; PG: the pool behind the BatchNorm sends its gradient along (PoolGrad)
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const float* __restrict__ x, const float* __restrict__ dy,
                                                             int C, int dps, const float* __restrict__ coef,
                                                             double* __restrict__ tab, int R, unsigned* __restrict__ ticket,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, PoolGrad pg) {
     __shared__ float red[256][8];
     const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
     const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
@@ -805,8 +834,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             v[u] = ld4<XH>(x, (p + (size_t)u * PL) * C + 4 * cq);
-            d[u] = ld4<GH>(dy, (p + (size_t)u * PL) * dps + 4 * cq);
+            d[u] = PG == 1 ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4<GH>(dy, (p + (size_t)u * PL) * dps + 4 * cq);
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = with_pool_grad<PG, GH>(d[u], pg, (unsigned)(p + (size_t)u * PL), cq, G);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             sg[0] = fmaf(d[u].x, (v[u].x - mean.x) * inv.x, sg[0]); sg[1] = fmaf(d[u].y, (v[u].y - mean.y) * inv.y, sg[1]);
@@ -817,7 +848,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
     if (blockIdx.x == gridDim.x - 1)
         for (size_t p = nfull * chunk + pl; p < npix; p += PL) {
             const float4 v = ld4<XH>(x, p * C + 4 * cq);
-            const float4 d = ld4<GH>(dy, p * dps + 4 * cq);
+            const float4 d = with_pool_grad<PG, GH>(PG == 1 ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4<GH>(dy, p * dps + 4 * cq), pg, (unsigned)p, cq, G);
             sg[0] = fmaf(d.x, (v.x - mean.x) * inv.x, sg[0]); sg[1] = fmaf(d.y, (v.y - mean.y) * inv.y, sg[1]);
             sg[2] = fmaf(d.z, (v.z - mean.z) * inv.z, sg[2]); sg[3] = fmaf(d.w, (v.w - mean.w) * inv.w, sg[3]);
             sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
@@ -844,18 +875,18 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
     }
 }
 
-template <bool DH, bool XH, bool GH>      // DH: dx is stored as bf16 (never accumulated into); XH / GH: x / dy are
+template <bool DH, bool XH, bool GH, int PG>      // DH: dx is stored as bf16 (never accumulated into); XH / GH: x / dy are; PG: see PoolGrad
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dx, int C, int dps, int acc,
                                                            const float* __restrict__ coef, const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                           float inv_n, int mask, float alpha) {
+                                                           float inv_n, int mask, float alpha, PoolGrad pg) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int G = C / 4, cq = (int)(i % G);
     const size_t p = i / G;
     const float4 v = ld4<XH>(x, 4 * i);
-    const float4 d = ld4<GH>(dy, p * dps + 4 * cq);
+    const float4 d = with_pool_grad<PG, GH>(PG == 1 ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4<GH>(dy, p * dps + 4 * cq), pg, (unsigned)p, cq, G);
     const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
     const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * cq);
     const float4 dg = *reinterpret_cast<const float4*>(dgamma + 4 * cq), db = *reinterpret_cast<const float4*>(dbeta + 4 * cq);
@@ -993,6 +1024,24 @@ bool fast_bn_supported(const Model* m, const Op& o) {
     return o.type == OP_BN && bn_fast_ok(o.inA.d) && o.out.d.ps % 4 == 0 && o.out.g.ps % 4 == 0 && o.inA.g.ps == o.inA.d.C;
 }
 
+// the pool's backward rides in the backward passes of the BatchNorm in front of it (PoolGrad): decided when the backward pass reaches
+// the pool; fast_bn_bwd finds Op::pool_grad
+bool fast_pool_into_bn(Model* m, Op& pool, Op& bn) {
+    static const bool off = getenv("DNNCA_NO_POOL_BN_BWD") != nullptr;
+    if (off || bn.type != OP_BN || pool.type != OP_POOL || pool.k != 2 || !fast_bn_supported(m, bn)) return false;
+    if (bn.out.g.p != pool.inA.g.p || bn.out.g.C != pool.inA.g.C || !dense(pool.inA.g) || !dense(pool.out.g) || pool.out.g.h || pool.maskA) return false;
+    if (!(pool.pool_idx_valid && (pool.pool_idx || m->dry))) return false;          // this step's forward recorded the positions
+    if (bn.out.g.H % 2 || bn.out.g.W % 2 || (double)m->desc.max_batch * bn.out.g.H * bn.out.g.W * bn.out.g.W >= 4.0e9) return false;
+    // f32 tensors only.  (With bf16-stored tensors the routed gradient -- a quarter of f32 values and a byte per pooled element -- is a
+    // third more traffic for each of the two passes: measured on unet_big, bn_bwd_reduce + 28 us on the four launches concerned and
+    // the step 6.87 -> 6.93 ms, against 11.98 -> 11.82 ms on mulmo_unet.)
+    if (bn.inA.d.h || bn.out.g.h || bn.inA.g.h) return false;
+    pool.pool_idx_valid = false;
+    bn.pool_grad = &pool;
+    bn.pool_grad_acc = pool.accA;          // somebody (a skip connection's conv) wrote dy before the pool would have
+    return true;
+}
+
 bool fast_bn_bwd(Model* m, int B, Op& o) {
     if (!bn_fast_ok(o.inA.d) || o.out.g.ps % 4 || o.inA.g.ps != o.inA.d.C) return false;
     const int C = o.inA.d.C;
@@ -1005,21 +1054,40 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
     if (R > (int)nb) R = (int)nb;
     unsigned* ticket = reinterpret_cast<unsigned*>(m->bn_tab + Model::kBnTab);
     const bool xh = o.inA.d.h != 0, gh = o.out.g.h != 0, dh = o.inA.g.h != 0;
-    const double rb = tb * ((xh ? 0.5 : 1.0) + (gh ? 0.5 : 1.0));
-#define BNRED(XHv, GHv) LAUNCH(m, "bn_bwd_reduce", rb, tb,                                                                   \
-        hipLaunchKernelGGL((k_bn_bwd_reduce_fast<XHv, GHv>), dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C, \
-                           o.out.g.ps, o.coef, m->bn_tab, R, ticket, m->g + o.w_off, m->g + o.b_off))
-    if (xh) { if (gh) BNRED(true, true); else BNRED(true, false); }
-    else { if (gh) BNRED(false, true); else BNRED(false, false); }
+    const Op* pool = o.pool_grad;
+    o.pool_grad = nullptr;
+    const int pgm = pool ? (o.pool_grad_acc ? 2 : 1) : 0;
+    PoolGrad pg{};
+    if (pool) {
+        pg.dpool = pool->out.g.p;
+        pg.idx = reinterpret_cast<const unsigned*>(pool->pool_idx);
+        pg.H = o.inA.d.H; pg.W = o.inA.d.W;
+        pg.mW = (unsigned)(0xffffffffull / (unsigned)pg.W) + 1u;
+        pg.mH = (unsigned)(0xffffffffull / (unsigned)pg.H) + 1u;
+    }
+    // bytes: x, dy (not when the routed gradient is all there is), + a quarter of f32 pooled gradient and a byte per pooled element
+    const double pgb = pool ? tb * (0.25 + 0.0625) : 0.0;
+    const double rb = tb * ((xh ? 0.5 : 1.0) + (pgm == 1 ? 0.0 : (gh ? 0.5 : 1.0))) + pgb;
+    m->set_variant("p%d", pgm);
+#define BNRED(XHv, GHv, PGv) LAUNCH(m, "bn_bwd_reduce", rb, tb,                                                              \
+        hipLaunchKernelGGL((k_bn_bwd_reduce_fast<XHv, GHv, PGv>), dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C, \
+                           o.out.g.ps, o.coef, m->bn_tab, R, ticket, m->g + o.w_off, m->g + o.b_off, pg))
+    if (pgm) {          // (fast_pool_into_bn: f32 tensors)
+        if (pgm == 1) BNRED(false, false, 1); else BNRED(false, false, 2);
+    } else if (xh) { if (gh) BNRED(true, true, 0); else BNRED(true, false, 0); }
+    else { if (gh) BNRED(false, true, 0); else BNRED(false, false, 0); }
 #undef BNRED
     const size_t n4 = npix * (C / 4);
     const dim3 grid((unsigned)((n4 + 255) / 256));
-#define BNBWD(DHv, XHv, GHv) LAUNCH(m, "bn_bwd_apply", rb + tb * (DHv ? 0.5 : 1.0), 2 * tb,                                  \
-        hipLaunchKernelGGL((k_bn_bwd_apply_fast<DHv, XHv, GHv>), grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.g.p,     \
+    m->set_variant("p%d", pgm);
+#define BNBWD(DHv, XHv, GHv, PGv) LAUNCH(m, "bn_bwd_apply", rb + tb * (DHv ? 0.5 : 1.0), 2 * tb,                             \
+        hipLaunchKernelGGL((k_bn_bwd_apply_fast<DHv, XHv, GHv, PGv>), grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.g.p, \
                            o.inA.g.p, C, o.out.g.ps, DHv ? 0 : (int)o.accA, o.coef, m->p + o.w_off, m->g + o.w_off,          \
-                           m->g + o.b_off, (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha))
-#define BNBWD2(DHv, XHv) do { if (gh) BNBWD(DHv, XHv, true); else BNBWD(DHv, XHv, false); } while (0)
-    if (dh) { if (xh) BNBWD2(true, true); else BNBWD2(true, false); }
+                           m->g + o.b_off, (float)(1.0 / (double)npix), (int)o.maskA, o.mask_alpha, pg))
+#define BNBWD2(DHv, XHv) do { if (gh) BNBWD(DHv, XHv, true, 0); else BNBWD(DHv, XHv, false, 0); } while (0)
+    if (pgm) {
+        if (pgm == 1) BNBWD(false, false, false, 1); else BNBWD(false, false, false, 2);
+    } else if (dh) { if (xh) BNBWD2(true, true); else BNBWD2(true, false); }
     else { if (xh) BNBWD2(false, true); else BNBWD2(false, false); }
 #undef BNBWD2
 #undef BNBWD

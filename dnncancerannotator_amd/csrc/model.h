@@ -43,6 +43,10 @@ struct Op {
     // (`elided`, decided by the forward pass, valid until the next one); the convs read the BatchNorm's INPUT and its coefficients.
     // src_bn[k]: the BatchNorm op that produces conv input k (-1: none); out_readers: the ops that read this op's output tensor
     bool elided = false;
+    // BN: the max-pool behind this BatchNorm handed its backward pass over (fast_pool_into_bn): the BatchNorm's backward passes route
+    // the pooled gradient themselves; pool_grad_acc: dy already holds another reader's gradient (a skip connection)
+    const Op* pool_grad = nullptr;
+    bool pool_grad_acc = false;
     int src_bn[2] = {-1, -1};
     std::vector<int> out_readers;
     // pool: position (0..3, row-major in the 2x2 window) of each output's first maximum, written by the fused BN-apply + pool

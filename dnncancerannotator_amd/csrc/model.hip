@@ -739,6 +739,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                         i -= 2;
                         break;
                     }
+                    if (!generic && i > 0 && fast_pool_into_bn(this, o, ops[i - 1])) break;   // rides in the backward passes of the BatchNorm in front of it
                     if (!generic && i > 0 && fast_pool_fold(this, o, ops[i - 1])) break;      // rides in the next launch (the conv's backward)
                     if (!generic && fast_pool_bwd(this, B, o, bytes)) break;
                     if (!all_f32(o)) return DNNCA_ESTATE;
