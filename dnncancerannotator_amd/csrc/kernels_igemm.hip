@@ -399,6 +399,18 @@ __global__ __launch_bounds__(256) void k_ig_wgrad(WgArgs p) {
 // pixels come back as zeros without branches) are issued into registers before a tile's MFMAs and written to LDS after
 // them; the 13 LDS operand words of K-step s+1 are loaded before the 36 MFMAs of step s.
 constexpr unsigned WG_FLAGS = 0x00020000u, WG_OOB = 0x80000000u;
+// phase stamps of k_ig_wgrad2 / k_ig_conv3 (tuning builds only; tools/wg_stamps.py): block 0, thread 0, the first 64 tiles / items
+#ifdef DNNCA_TUNING
+__device__ unsigned long long g_wg_stamps[64 * 8];
+__device__ __forceinline__ unsigned long long wg_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define WGSTAMP(item, ph) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (item) < 64) g_wg_stamps[(item) * 8 + (ph)] = wg_now(); } while (0)
+#else
+#define WGSTAMP(item, ph) do { } while (0)
+#endif
 typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
 
 // NWV = 8: eight waves (two per SIMD), the additional four split the tile's pixels (K) further -- for the narrow tiles whose
@@ -517,22 +529,36 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
 
     int tile = blockIdx.x;
     if (tile < ntiles) issue(tile);
+    int wg_it = 0;
 #pragma unroll 1
-    for (; tile < ntiles; tile += p.psplit) {
+    for (; tile < ntiles; tile += p.psplit, ++wg_it) {
+        WGSTAMP(wg_it, 0);
         lds_barrier();              // the previous tile's operand reads are complete
+        WGSTAMP(wg_it, 1);
         commit();
+        WGSTAMP(wg_it, 2);
         issue(tile + p.psplit);
+        WGSTAMP(wg_it, 3);
         lds_barrier();
+        WGSTAMP(wg_it, 4);
         float a0[9], b0[NN], a1[9], b1[NN];
         load_step(0, a0, b0);
 #pragma unroll 1
         for (int s = 0; s < NKS; s += 2) {
+            // the scheduling fences keep a step's operand reads in front of the previous step's MFMAs (hipcc sinks them to their
+            // first use otherwise: tools/wg_stamps.py read 400 ticks of exposed LDS latency per 1152-tick step on the one wave a SIMD has)
             load_step(s + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_step(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
             load_step(s + 2 < NKS ? s + 2 : 0, a0, b0);      // past the last step: a harmless reload
+            __builtin_amdgcn_sched_barrier(0);
             mfma_step(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        WGSTAMP(wg_it, 5);
     }
+    WGSTAMP(wg_it < 63 ? wg_it : 63, 6);
     // the WK pixel-split waves of a channel tile first add up inside the block (through the staged-tile LDS, one wave set
     // at a time), then wave set 0 adds into the gradient (copy blockIdx.x % nbuckets of it)
     if (WK > 1) {
@@ -2844,6 +2870,10 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
 }  // namespace dnnca
 
 #ifdef DNNCA_TUNING
+extern "C" int dnnca_debug_wg_stamps(unsigned long long* out, int n) {
+    if (n > 64 * 8) n = 64 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dnnca::ig::g_wg_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
 extern "C" int dnnca_debug_ig_stamps(unsigned long long* out, int n) {
     if (n > 64 * 8) n = 64 * 8;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(dnnca::igb::g_ig_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
