@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
     static_assert(NPX % (4 * WK) == 0 && (NPX / 4 / WK) % 2 == 0, "K-steps per wave");
     constexpr int NKS = NPX / 4 / WK;                                                   // K-steps per wave per tile
     constexpr int XF = PPATCH * XS + 16, GF = NPX * GS;
-    constexpr int RF = MW * (9 * NN + 1) * 256;          // buffer of the in-block reduction (overlays the staged tiles)
+    constexpr int RF = MW * 9 * NN * 256 > NT * 4 ? MW * 9 * NN * 256 : NT * 4;          // buffer of the in-block reductions (overlays the staged tiles)
     __shared__ __attribute__((aligned(16))) float smem[XF + GF > RF ? XF + GF : RF];
     float* x_lds = smem;
     float* g_lds = smem + XF;
@@ -435,7 +435,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
     const int m16 = lane & 15, q = lane >> 4;
     const int wm = wave % MW, wk = wave / MW;
     const int c0 = blockIdx.y * CIT, co0 = blockIdx.z * COT;
-    const bool do_bias = p.dbias && blockIdx.y == 0 && wm == 0;
+    // bias gradient = sum of dY over the pixels: every thread sums the channel quad it stages (the same one for every element: NT is a
+    // multiple of GQ), folded through LDS at the end.  (As an all-ones MFMA operand it was a branch inside the K-step loop.)
+    const bool do_bias = p.dbias && blockIdx.y == 0;          // block-uniform
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     const int tiles_y = (p.H + TYW - 1) / TYW;
     const FastDiv d_tx(p.tiles_x), d_ty(tiles_y);
     const int ntiles = p.tiles_x * tiles_y * p.B;
@@ -443,13 +446,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(npix * p.cs * 4), WG_FLAGS);
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (unsigned)(npix * p.cout * 4), WG_FLAGS);
 
-    f32x4 acc[9][NN], accb[NN];
+    f32x4 acc[9][NN];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < NN; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NN; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // staging geometry: X element u = patch pixel (tid + 256u) / XQ, float4 (tid + 256u) % XQ; dY likewise with GQ
     wg_u32x4 xr[XU], gr[GU];
@@ -506,6 +507,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
         for (int u = 0; u < GU; ++u) {
             const int i = tid + NT * u, px = i / GQ, n4 = i % GQ;
             if (px < NPX) *reinterpret_cast<wg_u32x4*>(g_lds + px * GS + 4 * n4) = gr[u];
+            if (do_bias && px < NPX) {          // (pixels outside the image were loaded as zeros)
+                const f32x4 gv = __builtin_bit_cast(f32x4, gr[u]);
+                bsum[0] += gv[0]; bsum[1] += gv[1]; bsum[2] += gv[2]; bsum[3] += gv[3];
+            }
         }
     };
     // operand words of K-step ks of this wave (4 pixels: tile row ks / 4, pixels 4 (ks % 4) ..)
@@ -521,10 +526,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < NN; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[j], acc[t][j], 0, 0, 0);
-        if (do_bias) {
-#pragma unroll
-            for (int j = 0; j < NN; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bv[j], accb[j], 0, 0, 0);
-        }
     };
 
     int tile = blockIdx.x;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
     // the WK pixel-split waves of a channel tile first add up inside the block (through the staged-tile LDS, one wave set
     // at a time), then wave set 0 adds into the gradient (copy blockIdx.x % nbuckets of it)
     if (WK > 1) {
-        float* red = smem + wm * ((9 * NN + 1) * 256);
+        float* red = smem + wm * (9 * NN * 256);
         for (int r = 1; r < WK; ++r) {
             __syncthreads();
             if (wk == r) {
@@ -572,8 +573,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
                     for (int j = 0; j < NN; ++j)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) red[((t * NN + j) * 4 + i) * 64 + lane] = acc[t][j][i];
-#pragma unroll
-                for (int j = 0; j < NN; ++j) red[9 * NN * 256 + j * 64 + lane] = accb[j][0];
             }
             __syncthreads();
             if (wk == 0) {
@@ -583,13 +582,23 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
                     for (int j = 0; j < NN; ++j)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) acc[t][j][i] += red[((t * NN + j) * 4 + i) * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < NN; ++j) accb[j][0] += red[9 * NN * 256 + j * 64 + lane];
             }
         }
     }
-    if (wk != 0) return;
     const size_t boff = (size_t)(p.nbuckets > 1 ? blockIdx.x % p.nbuckets : 0) * p.bucket_stride;
+    if (do_bias) {          // fold the NT / GQ threads of every channel quad (the tile buffers are free behind a barrier)
+        __syncthreads();
+        *reinterpret_cast<float4*>(smem + 4 * tid) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+        __syncthreads();
+        if (tid < COT) {
+            const int n4 = tid >> 2, k = tid & 3;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < NT / GQ; ++r) a += smem[4 * (n4 + GQ * r) + k];
+            atomicAdd(p.dbias + boff + co0 + tid, a);
+        }
+    }
+    if (wk != 0) return;
     // D[ci = 16 wm + 4q + i][co = 16j + m16]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -598,10 +607,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void k_ig_wgrad2(WgArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 atomicAdd(p.dw + boff + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
-    if (do_bias && q == 0) {
-#pragma unroll
-        for (int j = 0; j < NN; ++j) atomicAdd(p.dbias + boff + co0 + 16 * j + m16, accb[j][0]);     // row 0 of the all-ones A
-    }
 }
 
 // sum of the bucket copies of a small weight gradient: dst[i] += sum_b slabs[b][i]; the copies are left zeroed for the next use
