@@ -96,12 +96,15 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
         if (y >= p.H) continue;                 // wave-uniform
         float v[4][NN];
         bool ok[4];
-        size_t o[4];
+        // element offsets in 32 bits (conv3_path checks that every destination has fewer than 2^32 elements): with size_t the address
+        // arithmetic of the 16 NN stores was most of the epilogue -- 5.7 k of the 17.8 k ticks a 16-channel unit takes (tools/cv_stamps.py)
+        unsigned o[4];
+        const unsigned orow = (unsigned)(b * p.H + y) * (unsigned)p.W;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int x = x0 + 4 * q + i;
             ok[i] = x < p.W;
-            o[i] = (((size_t)b * p.H + y) * p.W + (ok[i] ? x : 0)) * cw + cl + m16;
+            o[i] = (orow + (unsigned)(ok[i] ? x : 0)) * (unsigned)cw + (unsigned)(cl + m16);
 #pragma unroll
             for (int j = 0; j < NN; ++j) v[i][j] = acc[r][j][i];
         }
@@ -805,8 +808,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* buf = lds + (it & 1) * BUF;
         float* other = lds + ((it & 1) ^ 1) * BUF;
+        WGSTAMP(it, 0);
         const Stage nx = next_stage();           // item it + 2
         if (norm_any) stage_coef(nx, n_sc_nxt, n_sh_nxt);          // used by the NEXT item's commits: the loads have a whole item to land
+        WGSTAMP(it, 1);
         const float* a_lds = buf + ((4 * wave) * (F3T + 2) + m16) * F3AS + q;
         const float* b_lds = buf + ABUF + q * BS + m16;
         // step s = (dx = s / 4, K-step k4 = s % 4): 6 A words (rows 0..5) + 3 x NN B words (dy = 0..2)
@@ -821,8 +826,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
                 for (int j = 0; j < NN; ++j) bw[dy][j] = b_lds[((dy * 3 + g) * CK + 4 * k4) * BS + 16 * j];
         };
         load_step(0, fa[0], fb[0]);
+        WGSTAMP(it, 2);
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
+#ifdef DNNCA_TUNING
+            if (s == 6) WGSTAMP(it, 3);
+#endif
             if (s + 1 < 12) load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
             if (s >= 1 && s <= 9) {                     // staging slice s-1 (nine slices: A elements 0..5, B elements 0..8)
                 const int v = s - 1;
@@ -842,11 +851,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ig_conv3(ConvArgs p) {
             a_in_cur = a_in_nxt;
             a_in_nxt = 0u;
         }
+        WGSTAMP(it, 4);
         lds_barrier();
+        WGSTAMP(it, 5);
     }
         {
             const Unit u = unit_of(k);
             conv3_epilogue<NN, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
+            WGSTAMP(it - 1, 6);
         }
     }
     if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);          // block-uniform; every block gets here
@@ -2485,7 +2497,9 @@ int ig_begin_backward(Model* m) {
 static bool conv3_path(const ig::ConvArgs& a, int cout, bool bf16) {
     // the persistent kernels address their sources with 32-bit byte offsets (bit 31 marks "outside the image")
     const int cmax = a.c_src0 > a.c_src1 ? a.c_src0 : a.c_src1;
-    const bool fits = (double)a.B * a.H * a.W * cmax * 4.0 < 2.0e9 && 9.0 * cout * (a.c_src0 + a.c_src1) * 4.0 < 2.0e9;
+    const int dmax = a.n_dst0 > a.n_dst1 ? a.n_dst0 : a.n_dst1;          // (the epilogue's 32-bit element offsets)
+    const bool fits = (double)a.B * a.H * a.W * cmax * 4.0 < 2.0e9 && 9.0 * cout * (a.c_src0 + a.c_src1) * 4.0 < 2.0e9 &&
+                      (double)a.B * a.H * a.W * dmax < 4.0e9;
     if (bf16) return fits && cout % 64 == 0 && a.c_src0 % 32 == 0 && a.c_src1 % 32 == 0 && a.n_dst0 % 64 == 0;
     return fits && !getenv("DNNCA_IGCONV1");
 }
