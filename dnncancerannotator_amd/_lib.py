@@ -125,6 +125,15 @@ SIGNATURES = {
 _lib = None
 
 
+def _hip_runtime_mapped():
+    """Is a HIP runtime already mapped into this process (somebody else may have initialised it)?"""
+    try:
+        with open('/proc/self/maps') as f:
+            return any('libamdhip64' in line for line in f)
+    except OSError:
+        return False
+
+
 def load():
     """dlopen libdnnca.so and declare every prototype.  Raises if the library has not been built."""
     global _lib
@@ -138,7 +147,13 @@ def load():
     # initialises, i.e. at the first HIP call behind this dlopen -- so this is the ONE place every process of the package passes
     # through in time: workers of `python -m dnncancerannotator_amd.launch`, ranks started by torch.distributed.run (bench.py),
     # single-GPU runs.  A value the caller exported wins.
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ:
+        os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+        if _hip_runtime_mapped():
+            import warnings
+            warnings.warn('libamdhip64 was already loaded when dnncancerannotator_amd set HSA_ENABLE_IPC_MODE_LEGACY=0: if the ROCm '
+                          'runtime has initialised, the setting is ignored and multi-process RCCL set-up may fail '
+                          '(hipIpcGetMemHandle: invalid argument).  Export it before starting the process.', RuntimeWarning)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

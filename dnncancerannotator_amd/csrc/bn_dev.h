@@ -4,16 +4,24 @@
 // plain reduction pass where no producer can) leave per-block partial sums.  Folding those used to be a launch of its own
 // (k_bn_fold_stats: 8 .. 128 blocks, 8 us, plus a dependent launch on the step's critical chain, 24 / 48 times per step of the
 // dense configurations).  Here the producer folds: every block ADDS its partial sums to one of R bucket rows of a small table
-// (double atomics, global_atomic_add_f64: the sum of the float partials is exact to double rounding whatever the order, so the
-// result does not depend on the order the blocks arrive in; a row meets blocks / R adders), draws a ticket when it is done, and
+// (double atomics, global_atomic_add_f64: the order the blocks arrive in moves the sum by double rounding only, ~1e-16 relative,
+// far below the float the result is rounded to; a row meets blocks / R adders), draws a ticket when it is done, and
 // the block that draws the last ticket folds the R rows, writes mean / variance / moving statistics / coefficients exactly as
 // g_bn_finalize does, and leaves table and ticket zeroed for the next user.  Table: Model::bn_tab (kBnTab doubles,
 // R * 2C <= kBnTab, R <= kBnRows), uses are stream-ordered.
 //
-// No device-scope fence: on gfx950 a release / acquire fence at agent scope is an L2 write-back / invalidate, and one per block
+// Ordering (round 4: made explicit; the workgroup-scope release fence that stood here compiles to NO wait on gfx950 outside
+// tgsplit mode, so nothing ordered a block's in-flight bucket adds before its ticket):
+//   1. every thread waits for its OWN outstanding memory operations with `s_waitcnt vmcnt(0)` -- a no-return
+//      global_atomic_add_f64 leaves vmcnt when the memory side has acknowledged (= performed) it;
+//   2. the workgroup barrier makes that hold for the whole block;
+//   3. only then thread 0 draws the ticket (a device-scope returning atomic, performed at the same place as the adds);
+//   4. the block that draws the last ticket reads the rows with device-scope loads, issued behind its ticket's return.
+// So every add of every block is performed before the last ticket is, and the fold (and its zeroing) comes behind that ticket.
+// No device-scope FENCE: on gfx950 a release / acquire fence at agent scope is an L2 write-back / invalidate, and one per block
 // costs more than the reduction it guards (measured on k_bn_bwd_reduce_fast: 74 us against 25).  Nothing is published through
-// plain stores: the partial sums travel as device-scope atomic adds, a block waits for its adds to be performed before it draws
-// its ticket, and the last block reads the rows with device-scope loads.
+// plain stores: the partial sums travel as device-scope atomic adds.  tests/test_isa_bn_order.py checks the compiled code of
+// every kernel that calls bn_last_block for step 1 (vmcnt(0) between the last bucket add and the barrier in front of the ticket).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -56,7 +64,7 @@ __device__ __forceinline__ double bn_fold_column(const double* tab, int R, int s
 constexpr int kBnGroups = 32;          // (the ticket array behind the table has 64 slots)
 __device__ __forceinline__ bool bn_last_block(unsigned* ticket, unsigned nblocks, unsigned bid) {
     __shared__ unsigned bn_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // this thread's adds have been performed
+    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): this thread's bucket adds have been performed (acknowledged)
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned G = nblocks < (unsigned)kBnGroups ? nblocks : (unsigned)kBnGroups, g = bid % G;

@@ -1,6 +1,8 @@
 // debug_tools.hip -- development aids (NOT part of include/dnnca.h and not used by the product path):
-// micro-benchmarks that calibrate what the conv kernels can expect from the f32 matrix pipe.
+// micro-benchmarks that calibrate what the conv kernels can expect from the f32 matrix pipe, and a read-back of the BatchNorm
+// reduction table for the tests.
 #include "model.h"
+#include <vector>
 
 using namespace dnnca;
 
@@ -65,5 +67,21 @@ int dnnca_debug_mfma_rate(void* model, int mode, int nch, int blocks, int iters,
     return DNNCA_OK;
 }
 
+// test aid (tests/test_engine_gpu.py): what the self-folding BatchNorm reductions left in their table (csrc/bn_dev.h) -- the bucket
+// rows and the ticket counters must read back as zero after every step.  Synchronises the stream.
+int dnnca_debug_bn_table(void* model, double* abs_sum, unsigned* ticket_sum, int* allocated) {
+    MODEL(model);
+    *abs_sum = 0.0;
+    *ticket_sum = 0u;
+    *allocated = M->bn_tab != nullptr;
+    if (!M->bn_tab) return DNNCA_OK;
+    HIP_TRY(hipStreamSynchronize(M->stream));
+    std::vector<double> h(Model::kBnTab + 32);
+    HIP_TRY(hipMemcpy(h.data(), M->bn_tab, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < Model::kBnTab; ++i) *abs_sum += h[i] < 0 ? -h[i] : h[i];
+    const unsigned* t = reinterpret_cast<const unsigned*>(h.data() + Model::kBnTab);
+    for (int i = 0; i < 64; ++i) *ticket_sum += t[i];
+    return DNNCA_OK;
+}
 
 }  // extern "C"

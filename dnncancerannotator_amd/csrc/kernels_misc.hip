@@ -862,8 +862,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
         for (int l = 0; l < PL; ++l) a += red[l * G + (c >> 2)][4 * which + (c & 3)];
         atomicAdd(row + o, (double)a);
     }
-    // ticket: a block's adds have been performed (device-scope atomics, waited for) before its ticket is drawn; the last block reads
-    // the rows with device-scope loads.  No device-scope FENCE anywhere: on gfx950 that is an L2 write-back / invalidate per block,
+    // ticket: a block's adds have been performed (device-scope atomics, each thread waits vmcnt(0) for its own in bn_last_block, then
+    // the barrier) before its ticket is drawn; the last block reads the rows with device-scope loads.  No device-scope FENCE anywhere: on gfx950 that is an L2 write-back / invalidate per block,
     // and 512 of them cost more than the reduction (74 us against 25); nothing here is published through plain stores.
     if (!bn_last_block(ticket, gridDim.x, blockIdx.x)) return;
     for (int o = threadIdx.x; o < 2 * C; o += 256) {

@@ -48,8 +48,11 @@ def main(argv=None, module='dnncancerannotator_amd'):
     key = uuid.uuid4().hex
     procs = []
     for rank in range(args.nproc):
-        # (HSA_ENABLE_IPC_MODE_LEGACY=0, which RCCL needs here, is set by _lib.load() in every worker before the first HIP call)
+        # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, which RCCL needs on this platform) goes into the child's environment, where it
+        # takes effect before process start whatever the worker imports first; _lib.load() sets it too (for ranks started by
+        # torch.distributed.run) but can only do so ahead of the first HIP call.  A value the caller exported wins.
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.nproc), DNNCA_RDZV_KEY=key)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, '-m', module] + args.rest, env=env))
     return supervise(procs)
 

@@ -50,14 +50,28 @@ def main():
         return self.device_model
     models.UNetAnnotator.build = build
 
+    # sizes (tests/test_dp_gloo.py sets them for the world-4 case: evaluation batches of 10 -> shards 3 + 3 + 2 + 2)
+    train_batch, val_n, val_batch = (int(os.environ.get(k, d)) for k, d in (('DP_TRAIN_BATCH', 4), ('DP_VAL_N', 11), ('DP_VAL_BATCH', 6)))
+    fail_rank, fail_step = int(os.environ.get('DP_FAIL_RANK', -1)), int(os.environ.get('DP_FAIL_STEP', 2))
+    if ctx.rank == fail_rank:
+        # a rank-local failure in the middle of a step (the reference's label assertion, utils/losses.py:91-99, is rank-local too):
+        # this rank raises BEFORE its all-reduce, its siblings are left waiting inside theirs -- the launcher must end them
+        real_step = FakeDeviceModel.train_step
+
+        def failing_step(self, x, y, lr, cfg):
+            if self.iterations + 1 == fail_step:
+                raise RuntimeError('injected failure on rank %d in step %d' % (ctx.rank, fail_step))
+            return real_step(self, x, y, lr, cfg)
+        FakeDeviceModel.train_step = failing_step
+
     H = W = 16
     xt, yt = O.synthetic_batch(8, H, W, 1, seed_x=3, seed_y=4)
     yt[1::2] = 0.0
     yt[1::2, 2:5, 3:6] = 1.0                                   # the two shards of a batch see different positive rates
-    train = data.ArrayDataset(xt, yt, 4, repeat=True)
-    xv, yv = O.synthetic_batch(11, H, W, 1, seed_x=5, seed_y=6)     # validation: batch 6 then a last batch of 5 (remainder)
+    train = data.ArrayDataset(xt, yt, train_batch, repeat=True)
+    xv, yv = O.synthetic_batch(val_n, H, W, 1, seed_x=5, seed_y=6)     # validation (default): batch 6 then a last batch of 5 (remainder)
     yv[7] = 0.0
-    val = data.ArrayDataset(xv, yv, 6)
+    val = data.ArrayDataset(xv, yv, val_batch)
     save = os.path.join(out_dir, 'run')
 
     m = engine.TFKerasModel(CONFIG)

@@ -87,6 +87,59 @@ def test_engine_world2(tmp_path):
     assert not os.path.exists(tmp_path / ('dnnca_rdzv_pytest_%d.id' % port))
 
 
+def test_engine_world4_with_uneven_evaluation_shards(tmp_path):
+    """The same job on FOUR gloo ranks: training batches of 8 (2 per replica), evaluation batches of 10 that do not divide --
+    shards 3 + 3 + 2 + 2 (engine.py:260-263: MirroredStrategy splits whatever batch it is handed; no sample may be dropped or counted
+    twice).  Same single-process emulation as the world-2 test."""
+    r, port = _spawn('dp_engine_worker.py', tmp_path, world=4, extra_env=dict(DP_TRAIN_BATCH='8', DP_VAL_N='20', DP_VAL_BATCH='10',
+                                                                             OMP_NUM_THREADS='1'))
+    assert all(x['built'] == [3] and x['max_batch'] == 3 for x in r)
+    per_rank = [[c[1] for c in x['calls'] if c[0] == 'eval'][:2] for x in r]
+    assert per_rank == [[3, 3], [3, 3], [2, 2], [2, 2]], per_rank
+    assert [c[1] for c in r[0]['calls'] if c[0] == 'train'][:4] == [2, 2, 2, 2]
+    for x in r[1:]:
+        assert np.array_equal(r[0]['params'], x['params'])
+        assert np.allclose(r[0]['loss'], x['loss'], rtol=0, atol=1e-15) and r[0]['val_loss'] == x['val_loss']
+        assert np.abs(np.array(r[0]['state']) - np.array(x['state'])).max() < 1e-7
+        assert r[0]['auc_counts'] == x['auc_counts'] and r[0]['eval']['loss'] == x['eval']['loss']
+        assert x['loss_presharded'] == x['loss']
+    assert np.abs(np.array(r[0]['params']) - np.array(r[0]['ref_params'])).max() < 1e-6
+    assert np.allclose(r[0]['loss'], r[0]['ref_loss'], rtol=1e-9)
+    assert np.allclose(r[0]['val_loss'], r[0]['ref_val_loss'], rtol=1e-9)
+    assert np.abs(np.array(r[0]['state']) - np.array(r[0]['ref_state'])).max() < 1e-6
+    assert r[0]['auc_counts'] == r[0]['ref_auc_counts']
+    assert np.array(r[0]['auc_counts']).sum(1).tolist() == [20 * 16 * 16] * 150          # every validation pixel once
+    assert r[0]['files'] == ['ckpt-2.data-00000-of-00001', 'ckpt-2.index', 'ckpt-4.data-00000-of-00001', 'ckpt-4.index']
+    assert not os.path.exists(tmp_path / ('dnnca_rdzv_pytest_%d.id' % port))
+
+
+def test_a_rank_that_raises_mid_step_ends_the_job(tmp_path):
+    """Four engine workers under launch.supervise; rank 2 raises in its second train step, in front of its all-reduce, so ranks
+    0, 1 and 3 sit inside theirs.  The launcher must return that rank's non-zero exit code in bounded time with every process
+    gone, and the rendezvous file of the job must not survive (it is removed right after the id exchange)."""
+    import time
+    sys.path.insert(0, os.path.dirname(HERE))
+    from dnncancerannotator_amd import launch
+    world, port = 4, _free_port()
+    procs, logs = [], []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), DNNCA_RDZV_KEY='pytest_%d' % port, TMPDIR=str(tmp_path), OMP_NUM_THREADS='1',
+                   DP_TRAIN_BATCH='8', DP_VAL_N='20', DP_VAL_BATCH='10', DP_FAIL_RANK='2', DP_FAIL_STEP='2')
+        logs.append(open(tmp_path / ('log%d.txt' % rank), 'wb'))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_engine_worker.py'), str(tmp_path)], env=env,
+                                      stdout=logs[-1], stderr=subprocess.STDOUT))
+    t0 = time.time()
+    code = launch.supervise(procs, grace=5.0)
+    for f in logs:
+        f.close()
+    assert code != 0, code
+    assert time.time() - t0 < 300 and all(p.poll() is not None for p in procs)
+    assert b'injected failure on rank 2 in step 2' in open(tmp_path / 'log2.txt', 'rb').read()
+    assert not any(os.path.exists(tmp_path / ('rank%d.json' % k)) for k in range(world))          # nobody finished the job
+    assert not [f for f in os.listdir(tmp_path) if f.startswith('dnnca_rdzv_')], os.listdir(tmp_path)
+
+
 def test_shard_bounds_cover_every_sample():
     from dnncancerannotator_amd import distributed
     for n in range(0, 20):

@@ -279,8 +279,9 @@ def test_batchnorm_reductions_fold_themselves_repeatably(gpu):
     """The BatchNorm reductions add their partial sums to a small table with double atomics and the last block of the same launch
     folds it and leaves it zeroed (csrc/bn_dev.h).  A hundred steps at learning rate 0 on one model: every step finds the table zeroed (a
     leftover would show up in the very next BatchNorm's statistics), so every step reproduces the first one's loss, BatchNorm
-    gradients and batch statistics -- the double sums of float partials do not depend on the order the blocks arrive in (what is
-    allowed to move is the float32 weight-gradient atomics of the convs)."""
+    gradients and batch statistics up to rounding -- the order the blocks arrive in moves a double sum of partials by double
+    rounding only (~1e-16 relative; what moves visibly is the float32 weight-gradient atomics of the convs).  At this size every
+    BatchNorm pass has <= 16 blocks: one member per ticket group, one adder per bucket row; the many-block case is the next test."""
     opts = dict(n_filters_first=64, n_downsample=2, rate=2, kernel_size=3, conv_stride=1, bn=True, padding='same')
     B, S = 2, 64
     spec = O.ModelSpec('unet', 1, **opts)
@@ -307,6 +308,71 @@ def test_batchnorm_reductions_fold_themselves_repeatably(gpu):
             assert np.abs(bn - first[1]).max() <= 1e-4 * np.abs(first[1]).max(), (dtype, step)          # (their inputs carry the conv atomics)
         assert 'bn_bwd_reduce' in set(r[0] for r in m.plan())
         m.close()
+
+
+def _bn_table(m):
+    """(sum |bucket rows|, sum of ticket counters, allocated?) of the self-folding BatchNorm table (debug_tools.hip; synchronises)"""
+    import ctypes as C
+    fn = m.lib.dnnca_debug_bn_table
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+    a, t, al = C.c_double(-1.0), C.c_uint(99), C.c_int(0)
+    assert fn(m.handle, C.byref(a), C.byref(t), C.byref(al)) == 0
+    return a.value, t.value, bool(al.value)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_batchnorm_self_fold_with_hundreds_of_blocks(gpu, dtype):
+    """The two-level ticket of csrc/bn_dev.h as configs/unet_big.yaml and configs/mulmo_unet.yaml run it: 2 x 512 x 512 x 64 gives
+    every stand-alone BatchNorm pass 512 blocks (16 members per ticket group, 32 adders per bucket row) and the conv epilogues one
+    block per CU, all finishing together.  (i) After every step the table and all ticket counters read back as ZERO (a block that
+    drew the last ticket before somebody's add had landed would leave that add behind).  (ii) The first BatchNorm's batch statistics
+    -- Conv2D(1 -> 64) + ReLU computed here in float64 numpy, mean and unbiased variance per channel (components.py:46-58, Keras
+    BatchNormalization's moving-statistics update with momentum 0.99) -- match to 2e-6.  (iii) Twenty steps at learning rate 0
+    reproduce the first one's loss, moving statistics and BatchNorm gradients."""
+    opts = dict(n_filters_first=64, n_downsample=1, rate=2, kernel_size=3, conv_stride=1, bn=True, padding='same')
+    B, S = 2, 512
+    spec = O.ModelSpec('unet', 1, **opts)
+    rng = np.random.default_rng(11)
+    x = rng.random((B, S, S, 1)).astype(np.float32)
+    y = (rng.random((B, S, S)) < 0.02).astype(np.float32)
+    m = gpu.DeviceModel('unet', 1, S, S, B, dtype=dtype, **opts)
+    m.init_glorot(seed=6)
+    named = m.named_params()
+    s0 = np.zeros_like(m.get_state())          # moving statistics start at 0: afterwards they are 0.01 x the batch statistics
+    cfg = m.loss_cfg(weight_mul=3.0)
+    # (ii) the reference for the first BatchNorm, float64
+    w = named['encoder.down0.conv0.kernel'].astype(np.float64).reshape(9, 64)
+    b = named['encoder.down0.conv0.bias'].astype(np.float64)
+    xp = np.pad(x[..., 0].astype(np.float64), ((0, 0), (1, 1), (1, 1)))
+    z = np.zeros((B, S, S, 64))
+    for t in range(9):
+        z += xp[:, t // 3:t // 3 + S, t % 3:t % 3 + S, None] * w[t]
+    z = np.maximum(z + b, 0.0).reshape(-1, 64)
+    n = z.shape[0]
+    mean_ref, var_ref = z.mean(0), z.var(0) * n / (n - 1)
+    del z
+    st_slices = dict(Hp.tensor_slices(spec, trainable=False))
+    first = None
+    for step in range(20):
+        m.set_state(s0)
+        out = m.train_step(x, y, 0.0, cfg)
+        leftover, tickets, allocated = _bn_table(m)
+        assert allocated and leftover == 0.0 and tickets == 0, (dtype, step, leftover, tickets)
+        g, st = m.get_grads().astype(np.float64), m.get_state().astype(np.float64)
+        bn = np.concatenate([g[sl] for n_, sl in Hp.tensor_slices(spec) if n_.endswith('.gamma') or n_.endswith('.beta')])
+        if first is None:
+            first = (out.loss, bn, st)
+            assert np.isfinite(bn).all() and np.abs(bn).max() > 0
+            mm, mv = st[st_slices['encoder.down0.bn0.moving_mean']] / 0.01, st[st_slices['encoder.down0.bn0.moving_variance']] / 0.01
+            assert np.abs(mm - mean_ref).max() <= 2e-6 * np.abs(mean_ref).max(), np.abs(mm - mean_ref).max()
+            assert np.abs(mv - var_ref).max() <= 2e-6 * np.abs(var_ref).max(), np.abs(mv - var_ref).max()
+            continue
+        assert abs(out.loss - first[0]) <= 1e-6 * max(1.0, abs(first[0])), (dtype, step)
+        assert np.abs(st - first[2]).max() <= 1e-6 * np.abs(first[2]).max(), (dtype, step)
+        assert np.abs(bn - first[1]).max() <= 2e-4 * np.abs(first[1]).max(), (dtype, step)          # (their inputs carry the conv atomics)
+    plan = set(r[0] for r in m.plan())
+    assert 'bn_bwd_reduce' in plan and ('bn_apply_pool' in plan or 'bn_stats' in plan), plan
+    m.close()
 
 
 @pytest.mark.parametrize('alpha', [0.0, 0.99])
