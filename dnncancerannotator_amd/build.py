@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdnnca.so')
-SOURCES = ['model.hip', 'kernels_generic.hip', 'kernels_mfma.hip', 'kernels_fused.hip', 'kernels_fused_bwd.hip', 'kernels_misc.hip', 'kernels_igemm.hip', 'kernels_first.hip', 'kernels_aug.hip', 'debug_tools.hip']
+SOURCES = ['model.hip', 'kernels_generic.hip', 'kernels_mfma.hip', 'kernels_fused.hip', 'kernels_fused_bwd.hip', 'kernels_misc.hip', 'kernels_igemm.hip', 'kernels_ig3x.hip', 'kernels_first.hip', 'kernels_aug.hip', 'debug_tools.hip']
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments arrive in SGPRs with the wave instead of through a cold
 # scalar load at its top (every launch of the unet.yaml step starts ~0.15 us earlier: 0.411 -> 0.409 ms per step, A/B on one box)
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-unused-result', '-mllvm', '-amdgpu-kernarg-preload-count=16']

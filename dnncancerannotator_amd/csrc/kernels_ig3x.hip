@@ -1,0 +1,381 @@
+// kernels_ig3x.hip -- fp32 3x3 convolutions (forward / data gradient) of the dense fp32 configurations (configs/mulmo_unet.yaml:
+// 16 .. 384 channels; components.py:46-52,122-127) on the BF16 matrix pipe, with fp32 results.
+//
+// gfx950 has no fast fp32 matrix path: v_mfma_f32_16x16x4_f32 runs at the vector rate (157 TFLOP/s), v_mfma_f32_16x16x32_bf16 at
+// sixteen times that.  An fp32 value is the EXACT sum of three bf16 values, f = h0 + h1 + h2 (h0 = bf16(f), h1 = bf16(f - h0),
+// h2 = bf16(f - h0 - h1): 8 + 8 + 8 significant bits with signed residuals; both subtractions are exact in fp32), and a product of
+// two bf16 values is exact in fp32.  So
+//         a b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + [a1 b2 + a2 b1 + a2 b2],   [...] <= 2^-24 |a b|,
+// and the six leading terms, accumulated in fp32 by the matrix pipe, give the convolution to fp32 accuracy (the dropped terms are
+// below one fp32 ulp of each product; the summation order differs from an fmaf chain like any other fp32 implementation's).
+// Six bf16 products per fp32 product at 16x the rate: 2.67x the fp32 matrix peak -- and the K = 32 of one MFMA holds TWO of them:
+// lanes q = 0, 1 (K 0..15) and q = 2, 3 (K 16..31) read different planes of the same 16 channels, so a 16-channel chunk costs three
+// MFMAs per tap and 16 x 16 tile:
+//         (a0 | a1) . (b0 | b0)  +  (a0 | a1) . (b1 | b1)  +  (a0 | a2) . (b2 | b0).
+//
+// Structure: the persistent scheme of ig::k_ig_conv3 (units = pixel tile x channel tile, K chunks of 16 input channels, raw buffer
+// loads with out-of-range offsets for the zero padding, register epilogue ig::conv3_epilogue with the fused BatchNorm statistics,
+// BatchNorm scale / shift applied while staging where the apply pass was elided).  The fp32 patch is split into three bf16 planes
+// WHILE IT IS STAGED (once per element, 3 x 8-byte LDS stores per 16-byte load); the weights arrive pre-split (k_ig3x_prep, once per
+// step: forward layout [plane][tap][co][ci], data-gradient layout [plane][8 - tap][ci][co]).  Three planes of both operands take 1.5x
+// the LDS of the fp32 kernel, so there is ONE LDS buffer: the next item's global loads fly during this item's MFMAs and are committed
+// between two barriers.
+#include <map>
+
+#include "fast.h"
+#include "ig_dev.h"
+#include "kernels.h"
+
+namespace dnnca {
+
+namespace ig3x {
+
+using ig::ConvArgs;
+using ig::lds_barrier;
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KC = 16;                  // fp32 input channels per item = one K = 32 MFMA over two planes
+constexpr int T = 16;                   // tile width (pixels); rows: 4 per wave
+constexpr unsigned BUF_FLAGS = 0x00020000u, OOB = 0x80000000u;
+
+// f = h0 + h1 + h2 (see the header)
+__device__ __forceinline__ void split3(float f, bf16_t& h0, bf16_t& h1, bf16_t& h2) {
+    h0 = (bf16_t)f;
+    const float r1 = f - (float)h0;
+    h1 = (bf16_t)r1;
+    const float r2 = r1 - (float)h1;
+    h2 = (bf16_t)r2;
+}
+
+struct PrepDesc {
+    int w_off, cin, cout;
+};
+// per step: the three bf16 planes of every 3x3 conv kernel [t][ci][co], in the forward layout wf[pl][t][co][ci] (K = ci contiguous)
+// and the data-gradient layout wd[pl][8 - t][ci][co] (K = co contiguous); plane pl of a buffer starts at pl * pstride elements
+__global__ void k_ig3x_prep(const PrepDesc* __restrict__ descs, const float* __restrict__ params, bf16_t* __restrict__ wf,
+                            bf16_t* __restrict__ wd, unsigned pstride) {
+    const PrepDesc d = descs[blockIdx.y];
+    // 32 x 32 (ci, co) tiles go through LDS so that both layouts are written in 64-byte runs (see igb::k_igb_prep)
+    __shared__ float tile[32][33];
+    const int ntx = (d.cout + 31) / 32, nty = (d.cin + 31) / 32, ntiles = 9 * nty * ntx;
+    const int tx32 = threadIdx.x & 31, ty8 = threadIdx.x >> 5;          // 256 threads: 8 rows of 32
+    for (int id = blockIdx.x; id < ntiles; id += gridDim.x) {
+        const int t = id / (nty * ntx), r = id - t * (nty * ntx), ty = r / ntx, tx = r - ty * ntx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = ty * 32 + ty8 + 8 * k, co = tx * 32 + tx32;
+            float v = 0.f;
+            if (ci < d.cin && co < d.cout) {
+                v = params[d.w_off + ((size_t)t * d.cin + ci) * d.cout + co];
+                bf16_t h0, h1, h2;
+                split3(v, h0, h1, h2);
+                const size_t o = d.w_off + ((size_t)(8 - t) * d.cin + ci) * d.cout + co;
+                wd[o] = h0; wd[pstride + o] = h1; wd[2 * (size_t)pstride + o] = h2;
+            }
+            tile[ty8 + 8 * k][tx32] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = tx * 32 + ty8 + 8 * k, ci = ty * 32 + tx32;
+            if (ci < d.cin && co < d.cout) {
+                bf16_t h0, h1, h2;
+                split3(tile[tx32][ty8 + 8 * k], h0, h1, h2);
+                const size_t o = d.w_off + ((size_t)t * d.cout + co) * d.cin + ci;
+                wf[o] = h0; wf[pstride + o] = h1; wf[2 * (size_t)pstride + o] = h2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// MODE 0 forward, MODE 1 data gradient (the forward kernel on the flipped / transposed planes).  w3: the conv's plane 0,
+// [9][N channels][K channels] bf16 with K contiguous; planes 1, 2 at + pstride, + 2 pstride elements.
+// NW waves: 4 -> 16 x 16-pixel tiles (one wave per SIMD), 8 -> 32 x 16 (two per SIMD).  Channel tile 16 NN.
+template <int NN, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_conv3(ConvArgs p, const bf16_t* __restrict__ w3, unsigned pstride) {
+    constexpr int NT = 64 * NW, TR = 4 * NW, PATCHX = (TR + 2) * (T + 2);
+    constexpr int COT = 16 * NN;
+    constexpr int APL = PATCHX * KC;                 // bf16 elements per A plane: [patch pixel][16 channels], 32-byte rows
+    constexpr int BPL = 9 * COT * KC;                // per B plane: [tap][channel of the tile][16 K channels]
+    constexpr int BOFF = 3 * APL, DUMP = BOFF + 3 * BPL, BUF = DUMP + 64;      // + a dump row for the idle lanes of the last staging element
+    __shared__ __attribute__((aligned(16))) bf16_t lds[BUF];
+    __shared__ float bn_red[NW * 2 * COT];           // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
+    const int nco = nout / COT, ntiles = p.tiles_x * p.tiles_y * p.B, nunits = ntiles * nco;
+    const int nchunks = kin / KC;
+    const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+    const int my_units = (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_units <= 0) {          // (the launcher sizes the grid to the units: not reached)
+        if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);
+        return;
+    }
+
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    const unsigned nbytes0 = (unsigned)(npix * p.c_src0 * 4), nbytes1 = (unsigned)(npix * p.c_src1 * 4);
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc((void*)w3, 0, (unsigned)((2 * (size_t)pstride + (size_t)9 * nout * kin) * 2), BUF_FLAGS);
+
+    const FastDiv d_nco(nco), d_tx(p.tiles_x), d_ty(p.tiles_y);
+    struct Unit { int b, y0, x0, co0, tile; };
+    auto unit_of = [&](int k) {
+        const int id = blockIdx.x + k * gridDim.x;
+        int tile, cot;
+        if (xcd_map) {              // ids congruent mod 8 share an XCD: keep a tile's channel blocks there
+            const int xcd = id & 7, j = id >> 3, jq = d_nco.div(j);
+            cot = j - jq * nco;
+            tile = jq * 8 + xcd;
+        } else {
+            tile = d_nco.div(id);
+            cot = id - tile * nco;
+        }
+        Unit u;
+        const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x;
+        u.b = d_ty.div(trow);
+        const int by = trow - u.b * p.tiles_y;
+        u.x0 = bx * T; u.y0 = by * TR; u.co0 = cot * COT; u.tile = tile;
+        return u;
+    };
+
+    // ---- staging geometry of this thread.  A element v: patch pixel (tid >> 2) + (NT / 4) v, channels 4 (tid & 3) .. + 3 (one 16-byte
+    //      load, three 8-byte LDS stores).  B element v: 16-byte piece i = tid + NT v of the item's 3 x 9 x COT rows of 32 bytes --
+    //      LDS is filled linearly, the global offset of a piece is fixed per thread up to the item's (channel tile, K chunk).
+    constexpr int AU = (PATCHX * 4 + NT - 1) / NT, NPIECE = 3 * 9 * COT * 2, BU = (NPIECE + NT - 1) / NT;
+    const int c4 = tid & 3;
+    int a_ly[AU], a_lx[AU];
+#pragma unroll
+    for (int v = 0; v < AU; ++v) {
+        const int px = (tid >> 2) + (NT / 4) * v;
+        a_ly[v] = px / (T + 2);
+        a_lx[v] = px - a_ly[v] * (T + 2);
+        if (px >= PATCHX) a_ly[v] = -4096;          // never inside an image
+    }
+    unsigned b_off[BU];          // element offset of piece v inside the planes, without the item's part
+#pragma unroll
+    for (int v = 0; v < BU; ++v) {
+        const int i = tid + NT * v, rowi = i >> 1, n = rowi % COT, tp = rowi / COT;
+        const int plane = (tp * 57) >> 9, tap = tp - 9 * plane;          // tp < 27
+        b_off[v] = i < NPIECE ? (unsigned)plane * pstride + (unsigned)((tap * nout + n) * kin + 8 * (i & 1)) : OOB;
+    }
+    u32x4 ar[AU], br[BU];
+    struct Stage { int b, y0, x0, cc, cs, c0; unsigned oob, wbase; __amdgpu_buffer_rsrc_t rs; };
+    int sg_k = 0, sg_cc = 0;
+    unsigned sg_oob = 0u;
+    Unit sg_u = unit_of(0);
+    auto next_stage = [&]() {
+        Stage st;
+        st.b = sg_u.b; st.y0 = sg_u.y0; st.x0 = sg_u.x0;
+        st.cc = sg_cc;
+        const bool second = st.cc >= p.c_src0;
+        st.cs = second ? p.c_src1 : p.c_src0;
+        st.c0 = second ? st.cc - p.c_src0 : st.cc;
+        st.oob = sg_oob;                    // past the last item: every offset out of range
+        st.wbase = (unsigned)(sg_u.co0 * kin + st.cc);
+        st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.src[1] : p.src[0]), 0, second ? nbytes1 : nbytes0, BUF_FLAGS);
+        sg_cc += KC;
+        if (sg_cc >= kin) {
+            sg_cc = 0;
+            ++sg_k;
+            if (sg_k < my_units) sg_u = unit_of(sg_k);
+            else sg_oob = OOB;
+        }
+        return st;
+    };
+    // normalise-on-load (MODE 0, ConvArgs::norm): scale / shift quad of the item in the registers + an inside-the-image bit per element
+    const bool norm_any = MODE == 0 && (p.norm[0] != nullptr || p.norm[1] != nullptr);          // block-uniform
+    float4 n_sc = make_float4(1.f, 1.f, 1.f, 1.f), n_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned a_in = 0u;
+    auto issue_item = [&](const Stage& st) {
+        a_in = 0u;
+#pragma unroll
+        for (int v = 0; v < AU; ++v) {
+            const int iy = st.y0 - 1 + a_ly[v], ix = st.x0 - 1 + a_lx[v];
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = (ok ? (unsigned)(((((st.b * p.H + iy) * p.W + ix) * st.cs) + st.c0 + 4 * c4) * 4) : OOB) | st.oob;
+            ar[v] = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
+            a_in |= ok ? (1u << v) : 0u;
+        }
+#pragma unroll
+        for (int v = 0; v < BU; ++v)
+            br[v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (b_off[v] == OOB ? OOB : (b_off[v] + st.wbase) * 2u) | st.oob, 0, 0);
+        if (norm_any) {
+            n_sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            n_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* nt = p.norm[st.cc >= p.c_src0 ? 1 : 0];          // uniform
+            if (nt) {
+                n_sc = *reinterpret_cast<const float4*>(nt + st.c0 + 4 * c4);
+                n_sh = *reinterpret_cast<const float4*>(nt + st.cs + st.c0 + 4 * c4);
+            }
+        }
+    };
+    auto commit_item = [&]() {
+#pragma unroll
+        for (int v = 0; v < AU; ++v) {
+            const int px = (tid >> 2) + (NT / 4) * v;
+            f32x4 f = __builtin_bit_cast(f32x4, ar[v]);
+            if (norm_any) {
+                const bool in = (a_in >> v) & 1u;
+                f[0] = in ? fmaf(f[0], n_sc.x, n_sh.x) : 0.f; f[1] = in ? fmaf(f[1], n_sc.y, n_sh.y) : 0.f;
+                f[2] = in ? fmaf(f[2], n_sc.z, n_sh.z) : 0.f; f[3] = in ? fmaf(f[3], n_sc.w, n_sh.w) : 0.f;
+            }
+            bf16x4 h0, h1, h2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bf16_t x0, x1, x2;
+                split3(f[e], x0, x1, x2);
+                h0[e] = x0; h1[e] = x1; h2[e] = x2;
+            }
+            bf16_t* dst = lds + (px < PATCHX ? px * KC : DUMP) + 4 * c4;          // idle lanes (last element only): the dump row
+            *reinterpret_cast<bf16x4*>(dst) = h0;
+            *reinterpret_cast<bf16x4*>(dst + (px < PATCHX ? APL : 16)) = h1;
+            *reinterpret_cast<bf16x4*>(dst + (px < PATCHX ? 2 * APL : 32)) = h2;
+        }
+#pragma unroll
+        for (int v = 0; v < BU; ++v) {
+            const int i = tid + NT * v;
+            *reinterpret_cast<u32x4*>(lds + (i < NPIECE ? BOFF + 8 * i : DUMP + 8 * (i & 7))) = br[v];
+        }
+    };
+
+    // ---- MFMA fragment addresses of this lane: rows of 16 channels, K half 8 (q & 1); the plane depends on q >> 1
+    const int hA = q >> 1;
+    const bf16_t* a_base = lds + ((4 * wave) * (T + 2) + m16) * KC + 8 * (q & 1);
+    const bf16_t* aX = a_base + hA * APL;               // (a0 | a1)
+    const bf16_t* aY = a_base + 2 * hA * APL;           // (a0 | a2)
+    const bf16_t* b_base = lds + BOFF + m16 * KC + 8 * (q & 1);
+    const bf16_t* bP[3] = {b_base, b_base + BPL, b_base + (hA ? 0 : 2 * BPL)};          // (b0 | b0), (b1 | b1), (b2 | b0)
+
+    f32x4 acc[4][NN];
+    issue_item(next_stage());
+#pragma unroll 1
+    for (int k = 0; k < my_units; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            commit_item();                       // the previous item's MFMAs have been fenced off by the barrier below
+            issue_item(next_stage());            // in flight during this item's MFMAs
+            lds_barrier();
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {        // dx-major: the six patch rows of a dx serve its three dy taps
+                bf16x8 fx[6], fy[6];
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) {
+                    fx[rr] = *reinterpret_cast<const bf16x8*>(aX + (rr * (T + 2) + g) * KC);
+                    fy[rr] = *reinterpret_cast<const bf16x8*>(aY + (rr * (T + 2) + g) * KC);
+                }
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int tap = dy * 3 + g;
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        bf16x8 fb[NN];
+#pragma unroll
+                        for (int j = 0; j < NN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bP[pr] + (tap * COT + 16 * j) * KC);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int j = 0; j < NN; ++j)
+                                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pr == 2 ? fy[r + dy] : fx[r + dy], fb[j], acc[r][j], 0, 0, 0);
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        const Unit u = unit_of(k);
+        ig::conv3_epilogue<NN, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
+    }
+    if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);          // block-uniform; every block gets here
+}
+
+}  // namespace ig3x
+
+// ================================================================================================ host side
+struct Ig3xPlan {
+    bool built = false;
+    std::vector<ig3x::PrepDesc> preps;
+    ig3x::PrepDesc* preps_dev = nullptr;
+    ig3x::bf16_t* wf = nullptr;        // [3][pstride]: forward layout, element offsets as in the parameter vector
+    ig3x::bf16_t* wd = nullptr;        // data-gradient layout
+    unsigned pstride = 0;
+    int max_w = 0;
+};
+static std::map<Model*, Ig3xPlan> g_ig3x;
+
+void ig3x_release(Model* m) { g_ig3x.erase(m); }
+
+// fp32 models only; DNNCA_NO_X3=1 keeps the exact-fp32 MFMA kernels (read once per process)
+bool ig3x_enabled(const Model* m) {
+    static const bool off = getenv("DNNCA_NO_X3") != nullptr;
+    return !off && m->desc.dtype == DNNCA_F32 && !(m->desc.flags & 1);
+}
+
+int ig3x_prepare(Model* m) {
+    if (!ig3x_enabled(m)) return DNNCA_OK;
+    Ig3xPlan& pl = g_ig3x[m];
+    if (!pl.built) {
+        pl.built = true;
+        for (const Op& o : m->ops) {
+            if (!ig_conv_supported(m, o)) continue;
+            ig3x::PrepDesc d{(int)o.w_off, o.inA.d.C + o.inB.d.C, o.out.d.C};
+            pl.preps.push_back(d);
+            const int n = 9 * ((d.cin + 31) / 32) * ((d.cout + 31) / 32);
+            if (n > pl.max_w) pl.max_w = n;
+        }
+        if (!pl.preps.empty()) {
+            pl.pstride = (unsigned)((m->nT + 15) / 16 * 16);
+            DN_TRY(m->alloc((void**)&pl.preps_dev, pl.preps.size() * sizeof(ig3x::PrepDesc)));
+            DN_TRY(m->alloc((void**)&pl.wf, (size_t)pl.pstride * 3 * 2 + 64));
+            DN_TRY(m->alloc((void**)&pl.wd, (size_t)pl.pstride * 3 * 2 + 64));
+            HIP_TRY(hipMemcpyAsync(pl.preps_dev, pl.preps.data(), pl.preps.size() * sizeof(ig3x::PrepDesc), hipMemcpyHostToDevice, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+    }
+    if (!pl.preps.empty()) {
+        int bx = pl.max_w;
+        if (bx > 512) bx = 512;
+        LAUNCH(m, "ig3x_prep", 16.0 * m->nT, 0,
+               hipLaunchKernelGGL(ig3x::k_ig3x_prep, dim3(bx, (unsigned)pl.preps.size()), dim3(256), 0, m->stream, pl.preps_dev, m->p,
+                                  pl.wf, pl.wd, pl.pstride));
+    }
+    return DNNCA_OK;
+}
+
+// launches the conv (mode 0 forward / 1 data gradient) described by `a` (tiles_x / tiles_y are set here) on the split-bf16 kernel;
+// false: not this path (the caller goes on to the exact-fp32 kernels)
+bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, int nw, const char* name, double bytes,
+                 double flops) {
+    if (!ig3x_enabled(m)) return false;
+    Ig3xPlan& pl = g_ig3x[m];
+    if (!m->dry && (!pl.wf || !pl.wd)) return false;
+    if (9.0 * cout * (a.c_src0 + a.c_src1) + 2.0 * pl.pstride > 1.0e9) return false;          // 32-bit byte offsets into the planes
+    ig::ConvArgs a2 = a;
+    a2.tiles_x = (a.W + ig3x::T - 1) / ig3x::T;
+    a2.tiles_y = (a.H + 4 * nw - 1) / (4 * nw);
+    const unsigned units = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / (16 * nn)));
+    const unsigned cap = (nw == 4 && nn <= 2) ? 512u : 256u;          // four-wave blocks with small channel tiles: two per CU (LDS)
+    const unsigned g = units < cap ? units : cap;
+    const ig3x::bf16_t* w3 = (mode == 0 ? pl.wf : pl.wd) + w_off;
+    m->set_variant("x3n%dw%d", nn, nw);
+#define X3(NNv, NWv)                                                                                                                      \
+    do {                                                                                                                                  \
+        if (mode == 0) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig3x::k_ig3x_conv3<NNv, 0, NWv>), dim3(g), dim3(64 * NWv), 0, m->stream, a2, w3, pl.pstride)); \
+        else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig3x::k_ig3x_conv3<NNv, 1, NWv>), dim3(g), dim3(64 * NWv), 0, m->stream, a2, w3, pl.pstride));            \
+    } while (0)
+    if (nn == 4) { if (nw == 8) X3(4, 8); else X3(4, 4); }
+    else if (nn == 2) { if (nw == 8) X3(2, 8); else X3(2, 4); }
+    else { if (nw == 8) X3(1, 8); else X3(1, 4); }
+#undef X3
+    return true;
+}
+
+}  // namespace dnnca

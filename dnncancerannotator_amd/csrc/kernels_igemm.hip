@@ -14,189 +14,11 @@
 #include "fast.h"
 #include "kernels.h"
 
+#include "ig_dev.h"
+
 namespace dnnca {
 
-// Division by a kernel-uniform divisor the persistent kernels repeat per tile: hipcc expands `/` into a ~25-instruction
-// dependent chain, which a kernel running one wave per SIMD cannot hide.  q = umulhi(n, ceil(2^32 / d)) is exact while
-// n * d < 2^32 (tile / unit / item counts are far below that).
-struct FastDiv {
-    unsigned d, m;
-    __device__ __forceinline__ explicit FastDiv(int dd) : d((unsigned)dd), m(dd > 1 ? (unsigned)(0xffffffffull / (unsigned)dd) + 1u : 0u) {}
-    __device__ __forceinline__ int div(int n) const { return d > 1 ? (int)__umulhi((unsigned)n, m) : n; }
-};
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 namespace ig {
-
-constexpr int TY = 8, TX = 16;          // block tile: 8 rows x 16 pixels = 128 GEMM rows, 32 per wave
-constexpr int CK = 16;                  // input channels per staged chunk
-constexpr int CKP = CK + 4;             // LDS pixel stride of the input patch (floats)
-constexpr int PATCH = (TY + 2) * (TX + 2);
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-struct ConvArgs {
-    const float* src[2];     // dense NHWC sources; chunk cc comes from src[cc >= c_src0]
-    int c_src0, c_src1;      // channels of the two sources (c_src1 = 0: one source)
-    const float* w;          // [9][Cin][Cout] (forward: the Keras kernel; data gradient: flipped/transposed copy)
-    const float* bias;       // forward: Cout floats (nullptr: none)
-    float* dst[2];           // output tensors; N-tiles below n_dst0 channels go to dst[0], the rest to dst[1]
-    int n_dst0, n_dst1;      // channels of the two destinations
-    const float* mask[2];    // data gradient: multiply by act'(mask tensor) (nullptr: no mask)
-    int acc[2];              // data gradient: accumulate into dst
-    int B, H, W;
-    int tiles_x, tiles_y;
-    float alpha;             // forward: activation slope (<0 none); data gradient: slope of the masked activation
-    // forward: batch statistics of the BatchNorm behind this conv ride in the epilogue of the persistent kernels, which fold them
-    // themselves (bn_dev.h; bnf.tab == nullptr: none)
-    BnSelfFold bnf;
-    // forward, k_ig_conv3: source k is the INPUT of a BatchNorm whose apply pass was elided; its scale / shift (norm[k][c],
-    // norm[k][c_srck + c]: the BatchNorm's coefficient table) are applied while the patch goes to LDS -- pixels outside the image
-    // stay zero, as the padding of the normalised tensor would be (nullptr: the source is used as it is)
-    const float* norm[2];
-    int src_half;            // the sources are stored as bf16 (View::h; k_igb_conv3 only)
-    int dst_half;            // forward, persistent kernels: dst[0] is stored as bf16 (the input of a BatchNorm, ig_plan_half)
-    int dsth[2];             // data gradient, persistent kernels: dst[k] is stored as bf16 (the gradient arriving at a BatchNorm)
-};
-
-// Epilogue of the persistent kernels (k_ig_conv3 / igb::k_igb_conv3), straight from the accumulator registers: lane (m16, q)
-// of wave w holds acc[r][j][i] = pixel (row 4w + r, column 4q + i) x channel 16j + m16 of the 16 x 16 tile, so one store
-// instruction writes four 64-byte channel runs.  (The earlier version transposed the tile through LDS to store 256-byte rows:
-// 64 LDS writes + 16 LDS reads per lane and up to five barriers cost as much as 1.7 K-chunks of MFMAs per tile.)
-//   MODE 0: + bias, activation; the BatchNorm behind the conv takes its batch statistics from here (ConvArgs::bnf): per-lane
-//           sums over the lane's 16 pixels, the four q groups folded by two wave shuffles, the NW waves through `red`
-//           ([NW][2 COT] floats of LDS) -- one barrier;
-//   MODE 1: accumulate into dst and multiply by act'(mask tensor) as requested.
-// (The backward sums of a BatchNorm were tried in the data-gradient epilogue too, twice: the extra read of the BatchNorm's
-// input there costs about what the reduction pass it replaces does -- with the LDS-staged epilogue and one wave per SIMD
-// 2.1 -> 3.2 ms of dgrad against 0.7 ms saved; with this epilogue and two waves per SIMD +0.44 ms of dgrad against 0.63 ms on
-// unet_big, and a net loss on mulmo_unet, where the fold of the per-tile partials also grows.  Round 3, with the self-folding
-// bucket rows of bn_dev.h and the sums taken from the stored bf16 values: 98 -> 192 us per launch -- the 16 two-byte loads per tile
-// row cannot move above the previous row's stores, four exposed round trips per unit.  DESIGN.md section 6.)
-template <int NN, int MODE, int NW = 4>
-__device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0, int tile,
-                                               float* red) {
-    constexpr int COT = 16 * NN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
-    const int which = co0 >= p.n_dst0;
-    const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co0 - p.n_dst0 : co0;
-    float* dst = p.dst[which];
-    const bool bn_on = MODE == 0 && p.bnf.tab != nullptr;
-    float bias[NN], bs[NN], bq[NN];
-#pragma unroll
-    for (int j = 0; j < NN; ++j) {
-        bias[j] = (MODE == 0 && p.bias) ? p.bias[co0 + 16 * j + m16] : 0.f;
-        bs[j] = 0.f;
-        bq[j] = 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int y = y0 + 4 * wave + r;
-        if (y >= p.H) continue;                 // wave-uniform
-        float v[4][NN];
-        bool ok[4];
-        // element offsets in 32 bits (conv3_path checks that every destination has fewer than 2^32 elements): with size_t the address
-        // arithmetic of the 16 NN stores was most of the epilogue -- 5.7 k of the 17.8 k ticks a 16-channel unit takes (tools/cv_stamps.py)
-        unsigned o[4];
-        const unsigned orow = (unsigned)(b * p.H + y) * (unsigned)p.W;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int x = x0 + 4 * q + i;
-            ok[i] = x < p.W;
-            o[i] = (orow + (unsigned)(ok[i] ? x : 0)) * (unsigned)cw + (unsigned)(cl + m16);
-#pragma unroll
-            for (int j = 0; j < NN; ++j) v[i][j] = acc[r][j][i];
-        }
-        if (MODE == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NN; ++j) {
-                    float t = v[i][j] + bias[j];
-                    if (p.alpha >= 0.f) t = t > 0.f ? t : p.alpha * t;
-                    if (p.dst_half) t = (float)(hbf16)t;          // the batch statistics are those of the stored values
-                    v[i][j] = t;
-                    if (bn_on && ok[i]) { bs[j] += t; bq[j] = fmaf(t, t, bq[j]); }
-                }
-        } else {
-            if (p.dsth[which]) {          // bf16 destination (never masked: the BatchNorm backward applies act')
-                hbf16* dh = reinterpret_cast<hbf16*>(dst);
-                if (p.acc[which]) {
-                    float t[4][NN];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < NN; ++j) t[i][j] = ok[i] ? (float)dh[o[i] + 16 * j] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < NN; ++j) v[i][j] += t[i][j];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NN; ++j)
-                        if (ok[i]) dh[o[i] + 16 * j] = (hbf16)v[i][j];
-                continue;
-            }
-            if (p.acc[which]) {
-                float t[4][NN];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NN; ++j) t[i][j] = ok[i] ? dst[o[i] + 16 * j] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NN; ++j) v[i][j] += t[i][j];
-            }
-            if (p.mask[which]) {
-                float t[4][NN];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NN; ++j) t[i][j] = ok[i] ? p.mask[which][o[i] + 16 * j] : 1.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NN; ++j) v[i][j] *= t[i][j] > 0.f ? 1.0f : p.alpha;
-            }
-        }
-        if (MODE == 0 && p.dst_half) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NN; ++j)
-                    if (ok[i]) reinterpret_cast<hbf16*>(dst)[o[i] + 16 * j] = (hbf16)v[i][j];
-            continue;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NN; ++j)
-                if (ok[i]) dst[o[i] + 16 * j] = v[i][j];
-    }
-    if (bn_on) {        // this unit's sums go to bucket row tile % R: [2 cw], first half sums, second half sums of squares
-#pragma unroll
-        for (int j = 0; j < NN; ++j) {
-            bs[j] += __shfl_xor(bs[j], 16); bs[j] += __shfl_xor(bs[j], 32);
-            bq[j] += __shfl_xor(bq[j], 16); bq[j] += __shfl_xor(bq[j], 32);
-            if (q == 0) {
-                red[wave * (2 * COT) + 16 * j + m16] = bs[j];
-                red[wave * (2 * COT) + COT + 16 * j + m16] = bq[j];
-            }
-        }
-        lds_barrier();
-        if (tid < 2 * COT) {
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) a += red[w * (2 * COT) + tid];
-            const int half = tid >= COT, c = half ? tid - COT : tid;
-            atomicAdd(bn_bucket(p.bnf, tile) + half * cw + cl + c, (double)a);
-        }
-    }
-}
 
 // MODE 0 forward, MODE 1 data gradient
 template <int NN, int MODE>
@@ -2318,7 +2140,10 @@ struct IgPlan {
 constexpr int WG_BUCKETS = 16, WG_SLAB_FLOATS = 131072 + 1024;
 static std::map<Model*, IgPlan> g_ig;
 
-void ig_release(Model* m) { g_ig.erase(m); }
+void ig_release(Model* m) {
+    g_ig.erase(m);
+    ig3x_release(m);
+}
 
 static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
 
@@ -2471,6 +2296,7 @@ int ig_prepare(Model* m) {
             HIP_TRY(hipStreamSynchronize(m->stream));
         }
     }
+    DN_TRY(ig3x_prepare(m));
     if (!pl.preps.empty()) {
         int bx = (pl.max_wb + 255) / 256;
         if (bx > 1024) bx = 1024;
@@ -2523,11 +2349,22 @@ static int ig_waves(const ig::ConvArgs& a, int cout) {
     return (forced == 8 || units8 >= 256) ? 8 : 4;
 }
 
+// waves per block of ig3x::k_ig3x_conv3: 8 (32 x 16-pixel tiles) once that still gives every CU a unit
+static int ig3x_waves(const ig::ConvArgs& a, int cout, int nn3) {
+    static const int forced = getenv("DNNCA_IG_NW") ? atoi(getenv("DNNCA_IG_NW")) : 0;        // tuning aid: 4 or 8
+    if (forced == 4 || forced == 8) return forced;
+    const long units8 = (long)((a.W + 15) / 16) * ((a.H + 31) / 32) * a.B * (cout / (16 * nn3));
+    return units8 >= 256 ? 8 : 4;
+}
+
 template <int MODE>
-static void launch_ig(Model* m, const ig::ConvArgs& a, int cout, const char* name, double bytes, double flops) {
+static void launch_ig(Model* m, const ig::ConvArgs& a, size_t w_off, int cout, const char* name, double bytes, double flops) {
     {   // pipelined persistent kernel: channel tile 16 nn3 must divide both destinations; 32-bit byte offsets
         const int nn3 = ig_nn3(a);
         if (conv3_path(a, cout, false)) {
+            // fp32 by three bf16 planes on the bf16 matrix pipe (kernels_ig3x.hip), unless switched off
+            if (ig3x_launch(m, MODE, a, w_off, cout, nn3, ig3x_waves(a, cout, nn3), MODE == 0 ? "ig3x_conv_fwd" : "ig3x_conv_dgrad", bytes, flops))
+                return;
             ig::ConvArgs a2 = a;
             const int nw = ig_waves(a, cout);
             a2.tiles_x = (a.W + ig::F3T - 1) / ig::F3T;
@@ -2635,7 +2472,7 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
         launch_igb<0>(m, a, pl.wf + o.w_off, o.out.d.C, "igb_conv_fwd", bytes, flops);
         return true;
     }
-    launch_ig<0>(m, a, o.out.d.C, "ig_conv_fwd", bytes, flops);
+    launch_ig<0>(m, a, o.w_off, o.out.d.C, "ig_conv_fwd", bytes, flops);
     return true;
 }
 
@@ -2755,7 +2592,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             if (use_bf16(m, o))
                 launch_igb<1>(m, a, pl.wd + o.w_off, CA + CB, "igb_conv_dgrad", out_bytes + in_bytes, flops);
             else
-                launch_ig<1>(m, a, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
+                launch_ig<1>(m, a, o.w_off, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
         }
     };
     // the fork sits in front of the data gradient (measured: forking behind it, so that the weight gradient meets only the next

@@ -70,7 +70,14 @@ def _run_case(gpu, name, force_generic):
         else:
             new = O.adam_step(O.unflatten(spec, p0.astype(np.float64)), O.unflatten(spec, gref.astype(np.float64)), {}, {}, 1, lr)
             paref = O.flatten(spec, new)
+        # ... a sign test wherever the gradient is well away from zero: |g| > 1000 eps AND > 20 x the error the gradient check above
+        # allows that variable (its own scale x GRAD_TOL + the float32-numpy floor: on the deep BatchNorm fixtures one ReLU / max-pool
+        # decision that float32 takes differently from float64 moves a variable by 1e-4 of its scale -- whichever float32 summation
+        # order is used -- and an entry of that size must not be asked for its sign)
         big = np.abs(gref) > 1000 * ADAM_EPS
+        for i, (n, sl) in enumerate(Hp.tensor_slices(spec)):
+            allowed = GRAD_TOL * np.abs(gref[sl]).max() + 10 * float(z['fp32_grad_abs_err_t'][i])
+            big[sl] &= np.abs(gref[sl]) > 20 * allowed
         assert np.abs(((pa - p0) - (paref - p0))[big]).max() <= 2e-3 * lr
         assert np.abs(pa - paref).max() <= 2.0 * lr + 1e-7   # the rest: never farther than a full step each way
         if m.n_state:
