@@ -40,6 +40,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KC = 16;                  // fp32 input channels per item = one K = 32 MFMA over two planes
+constexpr int kMaxBias = 1024;          // output channels at most (forward: the bias vector lives in LDS)
 constexpr int T = 16;                   // tile width (pixels); rows: 4 per wave
 constexpr unsigned BUF_FLAGS = 0x00020000u, OOB = 0x80000000u;
 
@@ -51,6 +52,19 @@ __device__ __forceinline__ void split3(float f, bf16_t& h0, bf16_t& h1, bf16_t& 
     const float r2 = r1 - (float)h1;
     h2 = (bf16_t)r2;
 }
+
+// phase stamps (tuning builds only: DNNCA_TUNING=1 python -m dnncancerannotator_amd.build; tools/x3_stamps.py): block 0, thread 0
+#ifdef DNNCA_TUNING
+__device__ unsigned long long g_x3_stamps[64 * 8];
+__device__ __forceinline__ unsigned long long x3_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define X3STAMP(item, ph) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (item) < 64) g_x3_stamps[(item) * 8 + (ph)] = x3_now(); } while (0)
+#else
+#define X3STAMP(item, ph) do { } while (0)
+#endif
 
 struct PrepDesc {
     int w_off, cin, cout;
@@ -94,6 +108,104 @@ __global__ void k_ig3x_prep(const PrepDesc* __restrict__ descs, const float* __r
     }
 }
 
+// sum over the 16 lanes of a DPP row (lanes that share q): quad swaps, then the two mirrors -- four v_add_f32 with DPP operands
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));     // row_mirror
+    return v;
+}
+
+// Epilogue straight from the accumulators, CHANNEL-major: the MFMAs run with the operands swapped (rows = channels, columns =
+// pixels), so lane (m16, q) of wave w holds acc[r][j][i] = channel 16 j + 4 q + i of pixel (row 4 w + r, column m16): four
+// consecutive channels of ONE pixel -- a 16-byte store, and the wave's store instruction covers 16 pixels x 64 bytes (one contiguous
+// KB where the tensor has 16 channels).  ig::conv3_epilogue's pixel-major layout needs a 4-byte store per value; at 16 channels per
+// tile its 16 stores per lane and unit took longer than the unit's MFMAs.  Same contract otherwise: MODE 0 bias + activation, the
+// batch statistics of the BatchNorm behind the conv (per-lane sums, DPP row sums over the 16 pixels, `red`, bucket adds; bn_dev.h);
+// MODE 1 accumulate / act' mask / two destinations.  fp32 tensors only (the bf16-stored variants belong to dtype bf16).
+template <int NN, int MODE, int NW>
+__device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0, int tile, float* red,
+                                           const float* bias_lds) {
+    constexpr int COT = 16 * NN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int which = co0 >= p.n_dst0;
+    const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co0 - p.n_dst0 : co0;
+    float* dst = p.dst[which];
+    const bool bn_on = MODE == 0 && p.bnf.tab != nullptr;
+    f32x4 bias[NN], bs[NN], bq[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        bias[j] = MODE == 0 ? *reinterpret_cast<const f32x4*>(bias_lds + co0 + 16 * j + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int x = x0 + m16;
+    const bool okx = x < p.W;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + 4 * wave + r;
+        if (y >= p.H) continue;                 // wave-uniform
+        // element offset in 32 bits (the launcher checks that every destination has fewer than 2^32 elements)
+        const unsigned o = ((unsigned)(b * p.H + y) * (unsigned)p.W + (unsigned)(okx ? x : 0)) * (unsigned)cw + (unsigned)(cl + 4 * q);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                f32x4 t = acc[r][j] + bias[j];
+                if (p.alpha >= 0.f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = t[i] > 0.f ? t[i] : p.alpha * t[i];
+                }
+                if (okx) {
+                    if (bn_on) {
+                        bs[j] += t;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) bq[j][i] = fmaf(t[i], t[i], bq[j][i]);
+                    }
+                    *reinterpret_cast<f32x4*>(dst + o + 16 * j) = t;
+                }
+            }
+        } else {
+            f32x4 t[NN], old[NN], mk[NN];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                t[j] = acc[r][j];
+                if (p.acc[which]) old[j] = okx ? *reinterpret_cast<const f32x4*>(dst + o + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.mask[which]) mk[j] = okx ? *reinterpret_cast<const f32x4*>(p.mask[which] + o + 16 * j) : f32x4{1.f, 1.f, 1.f, 1.f};
+            }
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                if (p.acc[which]) t[j] += old[j];
+                if (p.mask[which]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[j][i] *= mk[j][i] > 0.f ? 1.0f : p.alpha;
+                }
+                if (okx) *reinterpret_cast<f32x4*>(dst + o + 16 * j) = t[j];
+            }
+        }
+    }
+    if (bn_on) {        // this unit's sums go to bucket row tile % R: [2 cw], first half sums, second half sums of squares
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s1 = row16_sum(bs[j][i]), s2 = row16_sum(bq[j][i]);
+                if (m16 == 0) {
+                    red[wave * (2 * COT) + 16 * j + 4 * q + i] = s1;
+                    red[wave * (2 * COT) + COT + 16 * j + 4 * q + i] = s2;
+                }
+            }
+        lds_barrier();
+        if (tid < 2 * COT) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += red[w * (2 * COT) + tid];
+            const int half = tid >= COT, c = half ? tid - COT : tid;
+            atomicAdd(bn_bucket(p.bnf, tile) + half * cw + cl + c, (double)a);
+        }
+    }
+}
+
 // MODE 0 forward, MODE 1 data gradient (the forward kernel on the flipped / transposed planes).  w3: the conv's plane 0,
 // [9][N channels][K channels] bf16 with K contiguous; planes 1, 2 at + pstride, + 2 pstride elements.
 // NW waves: 4 -> 16 x 16-pixel tiles (one wave per SIMD), 8 -> 32 x 16 (two per SIMD).  Channel tile 16 NN.
@@ -105,10 +217,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
     constexpr int BPL = 9 * COT * KC;                // per B plane: [tap][channel of the tile][16 K channels]
     constexpr int BOFF = 3 * APL, DUMP = BOFF + 3 * BPL, BUF = DUMP + 64;      // + a dump row for the idle lanes of the last staging element
     __shared__ __attribute__((aligned(16))) bf16_t lds[BUF];
-    __shared__ float bn_red[NW * 2 * COT];           // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
+    __shared__ float bn_red[NW * 2 * COT];           // cross-wave fold of the fused BatchNorm statistics (epilogue_t)
+    // the bias vector, read by the epilogue through LDS: a global load there queues behind the next item's prefetch (vmcnt retires in
+    // order) and cost the epilogue of a 16-channel unit 4 k cycles of waiting (tools/x3_stamps.py)
+    __shared__ __attribute__((aligned(16))) float bias_lds[MODE == 0 ? kMaxBias : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4;
     const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
+    if (MODE == 0)
+        for (int c = tid; c < nout; c += NT) bias_lds[c] = p.bias ? p.bias[c] : 0.f;          // (visible behind the first item's barrier)
     const int nco = nout / COT, ntiles = p.tiles_x * p.tiles_y * p.B, nunits = ntiles * nco;
     const int nchunks = kin / KC;
     const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
@@ -254,6 +371,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
 
     f32x4 acc[4][NN];
     issue_item(next_stage());
+    int it = 0;
 #pragma unroll 1
     for (int k = 0; k < my_units; ++k) {
 #pragma unroll
@@ -261,38 +379,62 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
 #pragma unroll
             for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
+            X3STAMP(it, 0);
             commit_item();                       // the previous item's MFMAs have been fenced off by the barrier below
-            issue_item(next_stage());            // in flight during this item's MFMAs
+            X3STAMP(it, 1);
             lds_barrier();
+            X3STAMP(it, 2);
+            // the next item's loads: issued BEHIND the barrier -- their address arithmetic (1 - 3 k cycles per item in front of it,
+            // tools/x3_stamps.py) then runs beside the other waves' MFMAs instead of holding the whole block up
+            issue_item(next_stage());
+            X3STAMP(it, 3);
+            // 27 steps of 4 NN MFMAs: dx-major (g), per g first the (a0 | a1) fragments against (b0 | b0) and (b1 | b1) for the three dy taps,
+            // then the (a0 | a2) fragments against (b2 | b0).  Two register sets for both operands: the LDS reads of the NEXT step (B) and
+            // of the next A set are issued before this step's MFMAs (the compiler's own order put every read right in front of its MFMA
+            // behind an lgkmcnt(0): one exposed LDS round trip per step).
+            {
+                bf16x8 fa[2][6], fb[2][NN];
+                auto load_a = [&](bf16x8 (&a)[6], const bf16_t* base, int g) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {        // dx-major: the six patch rows of a dx serve its three dy taps
-                bf16x8 fx[6], fy[6];
+                    for (int rr = 0; rr < 6; ++rr) a[rr] = *reinterpret_cast<const bf16x8*>(base + (rr * (T + 2) + g) * KC);
+                };
+                auto load_b = [&](bf16x8 (&b)[NN], int pr, int tap) {
 #pragma unroll
-                for (int rr = 0; rr < 6; ++rr) {
-                    fx[rr] = *reinterpret_cast<const bf16x8*>(aX + (rr * (T + 2) + g) * KC);
-                    fy[rr] = *reinterpret_cast<const bf16x8*>(aY + (rr * (T + 2) + g) * KC);
-                }
+                    for (int j = 0; j < NN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bP[pr] + (tap * COT + 16 * j) * KC);
+                };
+                auto mfmas = [&](const bf16x8 (&a)[6], const bf16x8 (&b)[NN], int dy) {
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int tap = dy * 3 + g;
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int pr = 0; pr < 3; ++pr) {
-                        bf16x8 fb[NN];
+                        for (int j = 0; j < NN; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[r + dy], acc[r][j], 0, 0, 0);      // rows = channels, columns = pixels
+                };
+                load_a(fa[0], aX, 0);
+                load_b(fb[0], 0, 0);
 #pragma unroll
-                        for (int j = 0; j < NN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bP[pr] + (tap * COT + 16 * j) * KC);
+                for (int g = 0; g < 3; ++g) {
+                    // steps 0..5: X set (fa[0]); steps 6..8: Y set (fa[1]).  B sets alternate: step s of this g uses fb[(9 g + s) & 1]
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int j = 0; j < NN; ++j)
-                                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pr == 2 ? fy[r + dy] : fx[r + dy], fb[j], acc[r][j], 0, 0, 0);
+                    for (int s = 0; s < 9; ++s) {
+                        const int dy = s < 6 ? s >> 1 : s - 6, cur = (9 * g + s) & 1;
+                        if (s == 0) load_a(fa[1], aY, g);                         // this g's (a0 | a2) set, needed from step 6
+                        if (s == 6 && g < 2) load_a(fa[0], aX, g + 1);            // the next g's (a0 | a1) set
+                        if (s < 8 || g < 2) {                                     // B fragments of the next step
+                            const int s1 = s < 8 ? s + 1 : 0, g1 = s < 8 ? g : g + 1;
+                            const int dy1 = s1 < 6 ? s1 >> 1 : s1 - 6, pr1 = s1 < 6 ? (s1 & 1) : 2;
+                            load_b(fb[cur ^ 1], pr1, dy1 * 3 + g1);
+                        }
+                        mfmas(fa[s < 6 ? 0 : 1], fb[cur], dy);
                     }
                 }
             }
+            X3STAMP(it, 4);
             lds_barrier();
+            X3STAMP(it, 5);
         }
         const Unit u = unit_of(k);
-        ig::conv3_epilogue<NN, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
+        epilogue_t<NN, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red, bias_lds);
+        X3STAMP(it - 1, 6);
     }
     if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);          // block-uniform; every block gets here
 }
@@ -357,25 +499,45 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
     if (!ig3x_enabled(m)) return false;
     Ig3xPlan& pl = g_ig3x[m];
     if (!m->dry && (!pl.wf || !pl.wd)) return false;
+    if (a.src_half || a.dst_half || a.dsth[0] || a.dsth[1] || cout > ig3x::kMaxBias) return false;          // bf16-stored tensors: dtype bf16 only
     if (9.0 * cout * (a.c_src0 + a.c_src1) + 2.0 * pl.pstride > 1.0e9) return false;          // 32-bit byte offsets into the planes
     ig::ConvArgs a2 = a;
     a2.tiles_x = (a.W + ig3x::T - 1) / ig3x::T;
     a2.tiles_y = (a.H + 4 * nw - 1) / (4 * nw);
     const unsigned units = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / (16 * nn)));
-    const unsigned cap = (nw == 4 && nn <= 2) ? 512u : 256u;          // four-wave blocks with small channel tiles: two per CU (LDS)
-    const unsigned g = units < cap ? units : cap;
+    typedef void (*Kern)(ig::ConvArgs, const ig3x::bf16_t*, unsigned);
+    // [mode][nn index][nw index]
+    static const Kern kerns[2][3][2] = {
+        {{ig3x::k_ig3x_conv3<1, 0, 4>, ig3x::k_ig3x_conv3<1, 0, 8>}, {ig3x::k_ig3x_conv3<2, 0, 4>, ig3x::k_ig3x_conv3<2, 0, 8>},
+         {ig3x::k_ig3x_conv3<4, 0, 4>, ig3x::k_ig3x_conv3<4, 0, 8>}},
+        {{ig3x::k_ig3x_conv3<1, 1, 4>, ig3x::k_ig3x_conv3<1, 1, 8>}, {ig3x::k_ig3x_conv3<2, 1, 4>, ig3x::k_ig3x_conv3<2, 1, 8>},
+         {ig3x::k_ig3x_conv3<4, 1, 4>, ig3x::k_ig3x_conv3<4, 1, 8>}}};
+    const int ni = nn == 4 ? 2 : (nn == 2 ? 1 : 0), wi = nw == 8 ? 1 : 0;
+    const Kern kern = kerns[mode ? 1 : 0][ni][wi];
+    // a persistent kernel's grid is the number of blocks that are resident at once: several per CU where LDS and registers allow
+    // (a block alternates between committing an item and running its MFMAs; co-resident blocks fill each other's commit phases)
+    static int occ[2][3][2] = {};
+    int& oc = occ[mode ? 1 : 0][ni][wi];
+    if (oc == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64 * nw, 0) != hipSuccess || nb < 1) nb = 1;
+        static const int cap = getenv("DNNCA_X3_BLOCKS") ? atoi(getenv("DNNCA_X3_BLOCKS")) : 0;          // tuning aid
+        if (cap > 0 && nb > cap) nb = cap;
+        oc = nb;
+    }
+    const unsigned resident = 256u * (unsigned)oc;
+    const unsigned g = units < resident ? units : resident;
     const ig3x::bf16_t* w3 = (mode == 0 ? pl.wf : pl.wd) + w_off;
     m->set_variant("x3n%dw%d", nn, nw);
-#define X3(NNv, NWv)                                                                                                                      \
-    do {                                                                                                                                  \
-        if (mode == 0) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig3x::k_ig3x_conv3<NNv, 0, NWv>), dim3(g), dim3(64 * NWv), 0, m->stream, a2, w3, pl.pstride)); \
-        else LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig3x::k_ig3x_conv3<NNv, 1, NWv>), dim3(g), dim3(64 * NWv), 0, m->stream, a2, w3, pl.pstride));            \
-    } while (0)
-    if (nn == 4) { if (nw == 8) X3(4, 8); else X3(4, 4); }
-    else if (nn == 2) { if (nw == 8) X3(2, 8); else X3(2, 4); }
-    else { if (nw == 8) X3(1, 8); else X3(1, 4); }
-#undef X3
+    LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL(kern, dim3(g), dim3(64 * nw), 0, m->stream, a2, w3, pl.pstride));
     return true;
 }
 
 }  // namespace dnnca
+
+#ifdef DNNCA_TUNING
+extern "C" int dnnca_debug_x3_stamps(unsigned long long* out, int n) {
+    if (n > 64 * 8) n = 64 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dnnca::ig3x::g_x3_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif

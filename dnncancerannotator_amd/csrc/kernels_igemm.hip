@@ -2362,8 +2362,10 @@ static void launch_ig(Model* m, const ig::ConvArgs& a, size_t w_off, int cout, c
     {   // pipelined persistent kernel: channel tile 16 nn3 must divide both destinations; 32-bit byte offsets
         const int nn3 = ig_nn3(a);
         if (conv3_path(a, cout, false)) {
+            static const int x3_nn_cap = getenv("DNNCA_X3_NN") ? atoi(getenv("DNNCA_X3_NN")) : 4;          // tuning aid: channel tile at most 16 x this
+            const int nnx = nn3 > x3_nn_cap && (x3_nn_cap == 1 || x3_nn_cap == 2) ? x3_nn_cap : nn3;
             // fp32 by three bf16 planes on the bf16 matrix pipe (kernels_ig3x.hip), unless switched off
-            if (ig3x_launch(m, MODE, a, w_off, cout, nn3, ig3x_waves(a, cout, nn3), MODE == 0 ? "ig3x_conv_fwd" : "ig3x_conv_dgrad", bytes, flops))
+            if (ig3x_launch(m, MODE, a, w_off, cout, nnx, ig3x_waves(a, cout, nnx), MODE == 0 ? "ig3x_conv_fwd" : "ig3x_conv_dgrad", bytes, flops))
                 return;
             ig::ConvArgs a2 = a;
             const int nw = ig_waves(a, cout);
