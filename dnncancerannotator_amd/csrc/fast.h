@@ -72,12 +72,13 @@ struct BnSelfFold;
 // taken care of (Op::fused_stats_rows); false: not available (the BatchNorm then runs its own reduction pass)
 bool bn_self_fold_args(Model* m, Op& bn, int B, BnSelfFold* f);
 // kernels_ig3x.hip: the fp32 3x3 convs on the bf16 matrix pipe (three bf16 planes per operand, fp32-accurate)
-namespace ig { struct ConvArgs; }
+namespace ig { struct ConvArgs; struct WgArgs; }
 bool ig3x_enabled(const Model* m);
 int ig3x_prepare(Model* m);
 void ig3x_release(Model* m);
 bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, int nw, const char* name, double bytes,
                  double flops);
+bool ig3x_wgrad_launch(Model* m, ig::WgArgs w, int co, const char* name, double bytes, double flops);
 bool ig_tconv_supported(const Model* m, const Op& o);
 bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);
 bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);   // decides maskA/maskB/premasked for every op (static per model)

@@ -190,6 +190,21 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct WgArgs {
+    const float* x;          // one source, dense NHWC, cs channels
+    const float* dz;         // dense NHWC, cout channels
+    float* dw;               // [9][cin_total][cout] gradient (atomic accumulation; zeroed by the caller)
+    float* dbias;            // cout floats or nullptr
+    int cs, ci_off, cin_total, cout;
+    int B, H, W;
+    int tiles_x, tiles_y, psplit;
+    // same-address atomics execute one after the other (~56 ns each): when many blocks share a small gradient, block b adds
+    // into copy b % nbuckets of it (dw / dbias then point at copy 0, copies bucket_stride floats apart; k_wg_fold sums them)
+    int nbuckets, bucket_stride;
+    const float* norm;       // k_ig_wgrad2: x is the input of a BatchNorm whose apply pass was elided (scale norm[c], shift norm[cs + c]); nullptr: none
+};
+
 }  // namespace ig
 
 }  // namespace dnnca

@@ -439,6 +439,235 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
     if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);          // block-uniform; every block gets here
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[t][ci][co] = sum over pixels of X[pixel + t][ci] dY[pixel][co] (components.py:46-52 under GradientTape): M = input channels,
+// N = output channels, K = pixels, all nine taps at once -- the persistent scheme of ig::k_ig_wgrad2 (one block per CU walks its share
+// of the pixel tiles with the accumulators in registers; raw buffer loads, the next tile in registers while this one is consumed;
+// in-block reduction of the pixel-split waves; bucket copies for small gradients; BatchNorm scale / shift on load; bias gradient from
+// the staged dY quads) -- with both operands split into three bf16 planes while they are staged (X: [plane][patch pixel][ci],
+// dY: [plane][tile pixel][co]) and the K-contiguous (pixel-major) fragments taken out of the NHWC rows by ds_read_b64_tr_b16 as in
+// igb::k_igb_wgrad64.  One K = 32 MFMA step covers 16 pixels (two tile rows x 8 columns) of TWO planes: lane groups q = 0, 1 read
+// the first plane of the pair, q = 2, 3 the second, so per tap and 16 x 16 channel tile a step is the three MFMAs
+//         (x0 | x1) . (g0 | g0)  +  (x0 | x1) . (g1 | g1)  +  (x0 | x2) . (g2 | g0)
+// of the forward kernel.  Eight waves: MW input-channel tiles x WN output-channel halves x WK pixel splits; NJ 16-channel output
+// tiles per wave (at most 72 accumulator registers, two waves per SIMD).
+typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row0, const bf16_t* row1) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)row0);
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)row1);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// LDS row strides (bf16 elements): the eight rows a 32-lane half of a transposing read touches must fall into distinct 32-byte bank
+// groups -- stride / 16 elements odd
+constexpr int wg_stride(int ch) { return ch == 16 ? 16 : ch + 16; }
+constexpr int wg_lds_bytes(int cit, int cot, int tyw) { return 3 * 2 * ((tyw + 2) * (T + 2) * wg_stride(cit) + tyw * T * wg_stride(cot)) + 64; }
+// tile rows: 8 TM, as many as fit (the smaller the channel block, the taller the tile: the per-tile costs stay amortised)
+constexpr int wg_tm(int cit, int cot) {
+    return wg_lds_bytes(cit, cot, 32) <= 150 * 1024 ? 4 : (wg_lds_bytes(cit, cot, 16) <= 150 * 1024 ? 2 : 1);
+}
+
+template <int MW, int NJ, int WN, int WK>
+__global__ __launch_bounds__(512, 2) void k_ig3x_wgrad(ig::WgArgs p) {
+    static_assert(MW * WN * WK == 8, "eight waves");
+    constexpr int NT = 512;
+    constexpr int CIT = 16 * MW, COT = 16 * NJ * WN;
+    constexpr int TM = wg_tm(CIT, COT), TYW = 8 * TM, PW = T + 2, PPATCH = (TYW + 2) * PW, NPX = TYW * T;
+    constexpr int XS = wg_stride(CIT), GS = wg_stride(COT);
+    constexpr int XPL = PPATCH * XS, GPL = NPX * GS;                     // bf16 elements per plane
+    constexpr int XQ = CIT / 4, GQ = COT / 4;                            // channel quads per pixel
+    constexpr int XU = (PPATCH * XQ + NT - 1) / NT, GU = (NPX * GQ + NT - 1) / NT;
+    constexpr int NSTEP = NPX / 16;                                      // K = 32 steps per tile: (row pair, column half)
+    static_assert(NSTEP % WK == 0, "K steps per wave");
+    constexpr int NKS = NSTEP / WK;
+    constexpr int IMG = 3 * XPL + 3 * GPL + 32;                          // bf16 elements (+ a dump row)
+    constexpr int RF = MW * WN * 9 * NJ * 256;                           // floats of the in-block reduction (overlays the images)
+    constexpr int SMEM = IMG * 2 > RF * 4 ? IMG * 2 : RF * 4;
+    static_assert(SMEM <= 160 * 1024 && NT * 16 <= SMEM, "LDS");
+    static_assert(NT % XQ == 0 && NT % GQ == 0, "one channel quad per thread");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM];
+    bf16_t* ximg = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* gimg = ximg + 3 * XPL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int gq = (lane >> 2) & 3, gp = lane & 3;       // transposing read: lane 4 gq + gp of a group addresses row gq, columns 4 gp ..
+    const int wm = wave % MW, wn = (wave / MW) % WN, wk = wave / (MW * WN);
+    const int c0 = blockIdx.y * CIT, co0 = blockIdx.z * COT;
+    const bool do_bias = p.dbias && blockIdx.y == 0;          // block-uniform
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tiles_y = (p.H + TYW - 1) / TYW;
+    const FastDiv d_tx(p.tiles_x), d_ty(tiles_y);
+    const int ntiles = p.tiles_x * tiles_y * p.B;
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(npix * p.cs * 4), BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (unsigned)(npix * p.cout * 4), BUF_FLAGS);
+
+    f32x4 acc[9][NJ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging geometry: X element u = patch pixel (tid + NT u) / XQ, channel quad (tid + NT u) % XQ (the same quad for every u);
+    // dY likewise with GQ
+    u32x4 xr[XU], gr[GU];
+    const bool norm_on = p.norm != nullptr;
+    float4 n_sc = make_float4(1.f, 1.f, 1.f, 1.f), n_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (norm_on) {
+        n_sc = *reinterpret_cast<const float4*>(p.norm + c0 + 4 * (tid % XQ));
+        n_sh = *reinterpret_cast<const float4*>(p.norm + p.cs + c0 + 4 * (tid % XQ));
+    }
+    unsigned x_in = 0u;                        // bit u: element u of the tile in registers lies inside the image
+    auto issue = [&](int tile) {               // tile >= ntiles: stage nothing (every offset out of range)
+        x_in = 0u;
+        const unsigned oob = tile < ntiles ? 0u : OOB;
+        tile = tile < ntiles ? tile : 0;
+        const int trow = d_tx.div(tile), bx = tile - trow * p.tiles_x, b = d_ty.div(trow), by = trow - b * tiles_y;
+        const int x0 = bx * T, y0 = by * TYW;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + NT * u, px = i / XQ, c4 = i % XQ;
+            const int ly = px / PW, lx = px - ly * PW;
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            const bool ok = px < PPATCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = (ok ? (unsigned)(((((b * p.H + iy) * p.W + ix) * p.cs) + c0 + 4 * c4) * 4) : OOB) | oob;
+            xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+            x_in |= (ok && !oob) ? (1u << u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + NT * u, px = i / GQ, n4 = i % GQ;
+            const int ly = px / T, lx = px - ly * T;
+            const int iy = y0 + ly, ix = x0 + lx;
+            const bool ok = px < NPX && iy < p.H && ix < p.W;
+            const unsigned off = (ok ? (unsigned)(((((b * p.H + iy) * p.W + ix) * p.cout) + co0 + 4 * n4) * 4) : OOB) | oob;
+            gr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsg, off, 0, 0);
+        }
+    };
+    auto split_store = [&](f32x4 f, bf16_t* dst, int plane_stride) {
+        bf16x4 h0, h1, h2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16_t a0, a1, a2;
+            split3(f[e], a0, a1, a2);
+            h0[e] = a0; h1[e] = a1; h2[e] = a2;
+        }
+        *reinterpret_cast<bf16x4*>(dst) = h0;
+        *reinterpret_cast<bf16x4*>(dst + plane_stride) = h1;
+        *reinterpret_cast<bf16x4*>(dst + 2 * plane_stride) = h2;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + NT * u, px = i / XQ, c4 = i % XQ;
+            f32x4 f = __builtin_bit_cast(f32x4, xr[u]);
+            if (norm_on) {          // block-uniform
+                const bool in = (x_in >> u) & 1u;
+                f[0] = in ? fmaf(f[0], n_sc.x, n_sh.x) : 0.f; f[1] = in ? fmaf(f[1], n_sc.y, n_sh.y) : 0.f;
+                f[2] = in ? fmaf(f[2], n_sc.z, n_sh.z) : 0.f; f[3] = in ? fmaf(f[3], n_sc.w, n_sh.w) : 0.f;
+            }
+            if (px < PPATCH) split_store(f, ximg + px * XS + 4 * c4, XPL);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + NT * u, px = i / GQ, n4 = i % GQ;
+            const f32x4 gv = __builtin_bit_cast(f32x4, gr[u]);
+            if (px < NPX) {
+                split_store(gv, gimg + px * GS + 4 * n4, GPL);
+                if (do_bias) { bsum[0] += gv[0]; bsum[1] += gv[1]; bsum[2] += gv[2]; bsum[3] += gv[3]; }      // (pixels outside the image were loaded as zeros)
+            }
+        }
+    };
+    // per-lane bases of the transposing reads (bf16 elements): pixel column 4 (q & 1) + gq of the step's 8-column half; plane by q >> 1
+    const int hA = q >> 1;
+    const int xlane = (4 * (q & 1) + gq) * XS + 16 * wm + 4 * gp;
+    const int glane = (4 * (q & 1) + gq) * GS + 16 * NJ * wn + 4 * gp;
+    const bf16_t* xX = ximg + hA * XPL + xlane;                     // (x0 | x1)
+    const bf16_t* xY = ximg + 2 * hA * XPL + xlane;                 // (x0 | x2)
+    const bf16_t* gP[3] = {gimg + glane, gimg + GPL + glane, gimg + (hA ? 0 : 2 * GPL) + glane};      // (g0 | g0), (g1 | g1), (g2 | g0)
+
+    int tile = blockIdx.x;
+    issue(tile);
+#pragma unroll 1
+    for (; tile < ntiles; tile += p.psplit) {
+        lds_barrier();              // the previous tile's operand reads are complete
+        commit();
+        lds_barrier();
+        issue(tile + p.psplit);     // in flight during this tile's MFMAs (past the end: nothing)
+#pragma unroll 1
+        for (int s = 0; s < NKS; ++s) {
+            const int ks = wk + WK * s, rp = ks >> 1, ch = (ks & 1) * 8;          // tile rows 2 rp, 2 rp + 1; columns ch .. ch + 7
+            bf16x8 gv[3][NJ];
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    gv[pr][j] = tr_frag(gP[pr] + ((2 * rp) * T + ch) * GS + 16 * j, gP[pr] + ((2 * rp + 1) * T + ch) * GS + 16 * j);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t % 3;
+                const int o0 = ((2 * rp + dy) * PW + ch + dx) * XS, o1 = ((2 * rp + 1 + dy) * PW + ch + dx) * XS;
+                const bf16x8 ax = tr_frag(xX + o0, xX + o1), ay = tr_frag(xY + o0, xY + o1);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, gv[0][j], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, gv[1][j], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ay, gv[2][j], acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // the WK pixel-split waves of a (ci tile, co half) first add up inside the block (through the LDS of the images, one wave set at a
+    // time), then wave set 0 adds into the gradient (copy blockIdx.x % nbuckets of it)
+    float* red = reinterpret_cast<float*>(smem_raw) + (wm + MW * wn) * (9 * NJ * 256);
+    if (WK > 1) {
+        for (int r = 1; r < WK; ++r) {
+            __syncthreads();
+            if (wk == r) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) red[((t * NJ + j) * 4 + i) * 64 + lane] = acc[t][j][i];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[t][j][i] += red[((t * NJ + j) * 4 + i) * 64 + lane];
+            }
+        }
+    }
+    const size_t boff = (size_t)(p.nbuckets > 1 ? blockIdx.x % p.nbuckets : 0) * p.bucket_stride;
+    if (do_bias) {          // fold the NT / GQ threads of every channel quad (the images are free behind a barrier)
+        float* fs = reinterpret_cast<float*>(smem_raw);
+        __syncthreads();
+        *reinterpret_cast<float4*>(fs + 4 * tid) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+        __syncthreads();
+        if (tid < COT) {
+            const int n4 = tid >> 2, k = tid & 3;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < NT / GQ; ++r) a += fs[4 * (n4 + GQ * r) + k];
+            atomicAdd(p.dbias + boff + co0 + tid, a);
+        }
+    }
+    if (wk != 0) return;
+    // D[ci = 16 wm + 4q + i][co = 16 (NJ wn + j) + m16]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(p.dw + boff + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * (NJ * wn + j) + m16,
+                          acc[t][j][i]);
+}
+
 }  // namespace ig3x
 
 // ================================================================================================ host side
@@ -530,6 +759,36 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
     const ig3x::bf16_t* w3 = (mode == 0 ? pl.wf : pl.wd) + w_off;
     m->set_variant("x3n%dw%d", nn, nw);
     LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL(kern, dim3(g), dim3(64 * nw), 0, m->stream, a2, w3, pl.pstride));
+    return true;
+}
+
+
+// weight gradient of one source on the split-bf16 kernel; w: geometry and pointers filled by the caller (psplit is set here).
+// false: not this path.
+bool ig3x_wgrad_launch(Model* m, ig::WgArgs w, int co, const char* name, double bytes, double flops) {
+    if (!ig3x_enabled(m)) return false;
+    static const bool off = getenv("DNNCA_NO_X3_WGRAD") != nullptr;
+    if (off) return false;
+    const int cs = w.cs;
+    if (cs % 16 || co % 16) return false;
+    if ((double)w.B * w.H * w.W * (cs > co ? cs : co) * 4.0 >= 2.0e9) return false;          // 32-bit byte offsets
+    const int mw = cs % 64 == 0 ? 4 : (cs % 32 == 0 ? 2 : 1), nn = co % 64 == 0 ? 4 : (co % 32 == 0 ? 2 : 1);
+    const int rest = 8 / mw, wn = (nn >= 2 && rest >= 2) ? 2 : 1, nj = nn / wn, wk = rest / wn;
+    const int cit = 16 * mw, cot = 16 * nn;
+    const int tm = ig3x::wg_tm(cit, cot), tyw = 8 * tm;
+    w.tiles_x = (w.W + ig3x::T - 1) / ig3x::T;
+    const int nt = w.tiles_x * ((w.H + tyw - 1) / tyw) * w.B;
+    const int combos = (cs / cit) * (co / cot);
+    int ps = (256 + combos - 1) / combos;
+    if (ps > nt) ps = nt;
+    w.psplit = ps < 1 ? 1 : ps;
+    const dim3 g(w.psplit, cs / cit, co / cot);
+    m->set_variant("x3m%dj%dn%dk%d", mw, nj, wn, wk);
+#define WG3(MWv, NJv, WNv, WKv) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig3x::k_ig3x_wgrad<MWv, NJv, WNv, WKv>), g, dim3(512), 0, m->stream, w))
+    if (mw == 4) { if (nn == 4) WG3(4, 2, 2, 1); else if (nn == 2) WG3(4, 1, 2, 1); else WG3(4, 1, 1, 2); }
+    else if (mw == 2) { if (nn == 4) WG3(2, 2, 2, 2); else if (nn == 2) WG3(2, 1, 2, 2); else WG3(2, 1, 1, 4); }
+    else { if (nn == 4) WG3(1, 2, 2, 4); else if (nn == 2) WG3(1, 1, 2, 4); else WG3(1, 1, 1, 8); }
+#undef WG3
     return true;
 }
 

@@ -124,19 +124,7 @@ __global__ void k_ig_flip(const FlipDesc* __restrict__ descs, const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
-struct WgArgs {
-    const float* x;          // one source, dense NHWC, cs channels
-    const float* dz;         // dense NHWC, cout channels
-    float* dw;               // [9][cin_total][cout] gradient (atomic accumulation; zeroed by the caller)
-    float* dbias;            // cout floats or nullptr
-    int cs, ci_off, cin_total, cout;
-    int B, H, W;
-    int tiles_x, tiles_y, psplit;
-    // same-address atomics execute one after the other (~56 ns each): when many blocks share a small gradient, block b adds
-    // into copy b % nbuckets of it (dw / dbias then point at copy 0, copies bucket_stride floats apart; k_wg_fold sums them)
-    int nbuckets, bucket_stride;
-    const float* norm;       // k_ig_wgrad2: x is the input of a BatchNorm whose apply pass was elided (scale norm[c], shift norm[cs + c]); nullptr: none
-};
+// (WgArgs: ig_dev.h)
 
 // grid: x = pixel split, y = input-channel chunk (16), z = output-channel tile (16*NN)
 template <int NN>
@@ -2547,6 +2535,8 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
     #undef WG64
             } else if (!use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (w.cs > CO ? w.cs : CO) * 4.0 < 2.0e9 &&
                        !getenv("DNNCA_WGRAD1")) {
+                // fp32 by three bf16 planes on the bf16 matrix pipe (kernels_ig3x.hip), unless switched off
+                if (ig3x_wgrad_launch(m, w, CO, "ig3x_wgrad", bb, ff)) continue;
                 const int mw = w.cs % 64 == 0 ? 4 : (w.cs % 32 == 0 ? 2 : 1);
                 const int tm = (4 / mw) < (4 / nn) ? (4 / mw) : (4 / nn);
                 const int nt2 = tiles_x * ((o.out.d.H + 8 * tm - 1) / (8 * tm)) * B;

@@ -271,7 +271,7 @@ def test_dense_configs_at_real_widths_against_oracle(gpu, arch, C, opts, B, size
     assert np.abs(m.get_state() - O.flatten(spec, dict(params, **state), trainable=False)).max() <= 1e-5
     launches = [r[0] for r in m.plan()]
     plan = set(launches)
-    assert any(k.startswith('ig3x_conv') for k in plan) and any(k.startswith('ig_wgrad') for k in plan), plan
+    assert any(k.startswith('ig3x_conv') for k in plan) and any(k.startswith('ig3x_wgrad') for k in plan), plan
     # the BatchNorms whose every reader is a 3x3 conv have no apply pass: the convs (k_ig_conv3 forward, k_ig_wgrad2) read the
     # BatchNorm's input and apply scale / shift while they stage it (Op::elided) -- this comparison is what pins that path
     n_bn = sum(1 for n, _ in Hp.tensor_slices(spec) if n.endswith('.gamma'))
@@ -965,6 +965,6 @@ def test_dense_configs_full_resolution_tuned_vs_generic(gpu, arch, C, B, opts):
     assert np.median(list(errs.values())) <= 1e-2
     assert Hp.rel_err(tuned.get_state(), generic.get_state()) <= 1e-4          # BatchNorm moving statistics
     names = set(r[0] for r in tuned.plan())
-    assert {'ig3x_conv_fwd', 'ig_wgrad2', 'first_fwd', 'bn_apply_pool'} <= names
+    assert {'ig3x_conv_fwd', 'ig3x_wgrad', 'first_fwd', 'bn_apply_pool'} <= names
     tuned.close()
     generic.close()
