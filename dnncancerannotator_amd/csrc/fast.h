@@ -79,6 +79,7 @@ void ig3x_release(Model* m);
 bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, int nw, const char* name, double bytes,
                  double flops);
 bool ig3x_wgrad_launch(Model* m, ig::WgArgs w, int co, const char* name, double bytes, double flops);
+int ig3x_wgrad_psplit(const Model* m, const ig::WgArgs& w, int co);      // pixel-split blocks of that launch; 0: not this path
 bool ig_tconv_supported(const Model* m, const Op& o);
 bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next);
 bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, double flops);   // decides maskA/maskB/premasked for every op (static per model)

@@ -202,6 +202,12 @@ struct WgArgs {
     // same-address atomics execute one after the other (~56 ns each): when many blocks share a small gradient, block b adds
     // into copy b % nbuckets of it (dw / dbias then point at copy 0, copies bucket_stride floats apart; k_wg_fold sums them)
     int nbuckets, bucket_stride;
+    // plain = 1 (k_ig3x_wgrad, igb::k_igb_wgrad64w): no atomics at all -- block (x, y, z) STORES its sums into slab x of a per-launch
+    // set of psplit slabs (dw / dbias point at slab 0, slabs bucket_stride floats apart, laid out [9][cs][cout] + bias: cin_total = cs,
+    // ci_off = 0) and k_wg_fold_plain sums the slabs into the gradient.  A block's sums are 9 x (channel block) floats whatever the
+    // layer, so a 64 x 64-channel launch of 256 blocks drains 37.7 MB: 29 us as float atomics (1.3 TB/s at the memory side), 6 us as
+    // plain stores + a 10 us fold pass.
+    int plain;
     const float* norm;       // k_ig_wgrad2: x is the input of a BatchNorm whose apply pass was elided (scale norm[c], shift norm[cs + c]); nullptr: none
 };
 

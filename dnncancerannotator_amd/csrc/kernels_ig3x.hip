@@ -642,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void k_ig3x_wgrad(ig::WgArgs p) {
             }
         }
     }
-    const size_t boff = (size_t)(p.nbuckets > 1 ? blockIdx.x % p.nbuckets : 0) * p.bucket_stride;
+    const size_t boff = p.plain ? (size_t)blockIdx.x * p.bucket_stride : (size_t)(p.nbuckets > 1 ? blockIdx.x % p.nbuckets : 0) * p.bucket_stride;
     if (do_bias) {          // fold the NT / GQ threads of every channel quad (the images are free behind a barrier)
         float* fs = reinterpret_cast<float*>(smem_raw);
         __syncthreads();
@@ -653,19 +653,28 @@ __global__ __launch_bounds__(512, 2) void k_ig3x_wgrad(ig::WgArgs p) {
             float a = 0.f;
 #pragma unroll
             for (int r = 0; r < NT / GQ; ++r) a += fs[4 * (n4 + GQ * r) + k];
-            atomicAdd(p.dbias + boff + co0 + tid, a);
+            if (p.plain) p.dbias[boff + co0 + tid] = a;
+            else atomicAdd(p.dbias + boff + co0 + tid, a);
         }
     }
     if (wk != 0) return;
     // D[ci = 16 wm + 4q + i][co = 16 (NJ wn + j) + m16]
+    float* dwb = p.dw + boff + ((size_t)(p.ci_off + c0 + 16 * wm + 4 * q)) * p.cout + co0 + 16 * NJ * wn + m16;
+    if (p.plain) {          // block-uniform
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dwb[((size_t)t * p.cin_total + i) * p.cout + 16 * j] = acc[t][j][i];
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                atomicAdd(p.dw + boff + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * (NJ * wn + j) + m16,
-                          acc[t][j][i]);
+            for (int i = 0; i < 4; ++i) atomicAdd(dwb + ((size_t)t * p.cin_total + i) * p.cout + 16 * j, acc[t][j][i]);
 }
 
 }  // namespace ig3x
@@ -763,27 +772,47 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
 }
 
 
-// weight gradient of one source on the split-bf16 kernel; w: geometry and pointers filled by the caller (psplit is set here).
-// false: not this path.
-bool ig3x_wgrad_launch(Model* m, ig::WgArgs w, int co, const char* name, double bytes, double flops) {
+// the split-bf16 weight-gradient kernel's shape for one source: channel tiles, wave roles, pixel-split blocks; false: not this path
+struct Wg3Shape { int mw, nn, wn, nj, wk, tyw, ps; };
+static bool wg3_shape(const Model* m, const ig::WgArgs& w, int co, Wg3Shape* sh) {
     if (!ig3x_enabled(m)) return false;
     static const bool off = getenv("DNNCA_NO_X3_WGRAD") != nullptr;
     if (off) return false;
     const int cs = w.cs;
     if (cs % 16 || co % 16) return false;
     if ((double)w.B * w.H * w.W * (cs > co ? cs : co) * 4.0 >= 2.0e9) return false;          // 32-bit byte offsets
-    const int mw = cs % 64 == 0 ? 4 : (cs % 32 == 0 ? 2 : 1), nn = co % 64 == 0 ? 4 : (co % 32 == 0 ? 2 : 1);
-    const int rest = 8 / mw, wn = (nn >= 2 && rest >= 2) ? 2 : 1, nj = nn / wn, wk = rest / wn;
-    const int cit = 16 * mw, cot = 16 * nn;
-    const int tm = ig3x::wg_tm(cit, cot), tyw = 8 * tm;
-    w.tiles_x = (w.W + ig3x::T - 1) / ig3x::T;
-    const int nt = w.tiles_x * ((w.H + tyw - 1) / tyw) * w.B;
+    sh->mw = cs % 64 == 0 ? 4 : (cs % 32 == 0 ? 2 : 1);
+    sh->nn = co % 64 == 0 ? 4 : (co % 32 == 0 ? 2 : 1);
+    const int rest = 8 / sh->mw;
+    sh->wn = (sh->nn >= 2 && rest >= 2) ? 2 : 1;
+    sh->nj = sh->nn / sh->wn;
+    sh->wk = rest / sh->wn;
+    const int cit = 16 * sh->mw, cot = 16 * sh->nn;
+    sh->tyw = 8 * ig3x::wg_tm(cit, cot);
+    const int nt = ((w.W + ig3x::T - 1) / ig3x::T) * ((w.H + sh->tyw - 1) / sh->tyw) * w.B;
     const int combos = (cs / cit) * (co / cot);
     int ps = (256 + combos - 1) / combos;
     if (ps > nt) ps = nt;
-    w.psplit = ps < 1 ? 1 : ps;
-    const dim3 g(w.psplit, cs / cit, co / cot);
-    m->set_variant("x3m%dj%dn%dk%d", mw, nj, wn, wk);
+    sh->ps = ps < 1 ? 1 : ps;
+    return true;
+}
+
+// pixel-split blocks (= slabs in plain mode) of the launch ig3x_wgrad_launch would make; 0: not this path
+int ig3x_wgrad_psplit(const Model* m, const ig::WgArgs& w, int co) {
+    Wg3Shape sh;
+    return wg3_shape(m, w, co, &sh) ? sh.ps : 0;
+}
+
+// weight gradient of one source on the split-bf16 kernel; w: geometry and pointers filled by the caller (psplit is set here).
+// false: not this path.
+bool ig3x_wgrad_launch(Model* m, ig::WgArgs w, int co, const char* name, double bytes, double flops) {
+    Wg3Shape sh;
+    if (!wg3_shape(m, w, co, &sh)) return false;
+    const int mw = sh.mw, nn = sh.nn, cit = 16 * mw, cot = 16 * nn;
+    w.tiles_x = (w.W + ig3x::T - 1) / ig3x::T;
+    w.psplit = sh.ps;
+    const dim3 g(w.psplit, w.cs / cit, co / cot);
+    m->set_variant("x3m%dj%dn%dk%d%s", mw, sh.nj, sh.wn, sh.wk, w.plain ? "p" : "");
 #define WG3(MWv, NJv, WNv, WKv) LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL((ig3x::k_ig3x_wgrad<MWv, NJv, WNv, WKv>), g, dim3(512), 0, m->stream, w))
     if (mw == 4) { if (nn == 4) WG3(4, 2, 2, 1); else if (nn == 2) WG3(4, 1, 2, 1); else WG3(4, 1, 1, 2); }
     else if (mw == 2) { if (nn == 4) WG3(2, 2, 2, 2); else if (nn == 2) WG3(2, 1, 2, 2); else WG3(2, 1, 1, 4); }

@@ -444,6 +444,52 @@ __global__ __launch_bounds__(256) void k_wg_fold(float* __restrict__ slabs, int 
     else dbias[i - n_w] += s;
 }
 
+// WgArgs::plain: the sum of a launch's psplit slabs goes into the gradient.  A slab is [9][cs][cout] (+ cout bias sums when n_b > 0); the
+// gradient rows of this source sit at input channels ci_off .. ci_off + cs of [9][cin_total][cout].  One thread = four consecutive floats
+// of a slab; the slabs are not re-zeroed (every launch stores every element of every slab).
+template <int G>      // slab groups per block: 256 / G quads x G groups (small gradients: few quads, many slabs -> G = 16; large: G = 1)
+__global__ __launch_bounds__(256) void k_wg_fold_plain(const float* __restrict__ slabs, int nb, int stride, int cs, int cout, int cin_total,
+                                                       int ci_off, float* __restrict__ dw, float* __restrict__ dbias, int n_b) {
+    // thread (quad qi, group g) sums slabs g, g + G, ... (eight loads in flight); the groups meet in LDS
+    constexpr int Q = 256 / G;
+    __shared__ f32x4 red[G][Q + 1];
+    const int n_w = 9 * cs * cout;
+    const int qi = threadIdx.x % Q, g = threadIdx.x / Q;
+    const int i = 4 * (blockIdx.x * Q + qi);
+    const bool live = i < n_w + n_b;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        constexpr int U = 8;
+        for (int b0 = g; b0 < nb; b0 += G * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + G * u;
+                v[u] = *reinterpret_cast<const f32x4*>(slabs + (size_t)(b < nb ? b : g) * stride + i);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (b0 + G * u < nb) s += v[u];
+        }
+    }
+    if (G > 1) {
+        red[g][qi] = s;
+        __syncthreads();
+        if (g != 0) return;
+#pragma unroll
+        for (int k = 1; k < G; ++k) s += red[k][qi];
+    }
+    if (!live) return;
+    if (i < n_w) {
+        const int t = i / (cs * cout), r = i - t * (cs * cout);          // cout % 4 == 0: the quad stays inside one row
+        float* d = dw + ((size_t)t * cin_total + ci_off) * cout + r;
+        *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
+    } else {
+        float* d = dbias + (i - n_w);
+        *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
+    }
+}
+
 // forward / data gradient, fp32, persistent and software-pipelined: the f32 twin of igb::k_igb_conv3 (see there for the
 // scheme).  Block tile 16 x 16 pixels x 16*NN channels, K chunks of 16 input channels; per item 576*NN/4... MFMAs per
 // wave (4 M-tiles x NN N-tiles x 9 taps x 4 K-steps of v_mfma_f32_16x16x4_f32), walked dx-major: one step = (dx, K-step)
@@ -1788,14 +1834,24 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
         lds_barrier();
         buf ^= 1;
     }
-    // D[ci = 16 wm + 4q + i][co = 16 NJ wn + 16j + m16]
+    // D[ci = 16 wm + 4q + i][co = 16 NJ wn + 16j + m16]; plain: stores into slab blockIdx.x (WgArgs::plain), else atomics into the gradient
+    const size_t boff = p.plain ? (size_t)blockIdx.x * p.bucket_stride : 0;
+    float* dwb = p.dw + boff + ((size_t)(p.ci_off + c0 + 16 * wm + 4 * q)) * p.cout + co0 + m16;
+    if (p.plain) {          // block-uniform
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                atomicAdd(p.dw + ((size_t)t * p.cin_total + p.ci_off + c0 + 16 * wm + 4 * q + i) * p.cout + co0 + 16 * j + m16, acc[t][j][i]);
+                for (int i = 0; i < 4; ++i) dwb[((size_t)t * p.cin_total + i) * p.cout + 16 * j] = acc[t][j][i];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd(dwb + ((size_t)t * p.cin_total + i) * p.cout + 16 * j, acc[t][j][i]);
+    }
     if (do_bias) {          // fold the 512 / GQ threads of every channel quad (the tile buffers are free: the loop ended on a barrier)
         float* red = reinterpret_cast<float*>(&ximg2[0][0]);
         *reinterpret_cast<float4*>(red + 4 * tid) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
@@ -1805,7 +1861,8 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
             float a = 0.f;
 #pragma unroll
             for (int r = 0; r < 512 / GQ; ++r) a += red[4 * (n4 + GQ * r) + k];
-            atomicAdd(p.dbias + blockIdx.z * COB + tid, a);
+            if (p.plain) p.dbias[boff + blockIdx.z * COB + tid] = a;
+            else atomicAdd(p.dbias + blockIdx.z * COB + tid, a);
         }
     }
 }
@@ -2124,6 +2181,7 @@ struct IgPlan {
     igb::bf16_t* wd = nullptr;
     int max_wb = 0;
     float* wg_slabs = nullptr;       // WG_BUCKETS copies of a small layer's weight + bias gradient (ig_wgrad2; left zeroed by k_wg_fold)
+    std::map<std::pair<const void*, int>, std::pair<float*, size_t>> plain;      // (op, source) -> slabs of its plain-mode weight gradient, floats
 };
 constexpr int WG_BUCKETS = 16, WG_SLAB_FLOATS = 131072 + 1024;
 static std::map<Model*, IgPlan> g_ig;
@@ -2131,6 +2189,22 @@ static std::map<Model*, IgPlan> g_ig;
 void ig_release(Model* m) {
     g_ig.erase(m);
     ig3x_release(m);
+}
+
+// slabs of one weight-gradient launch in plain mode (WgArgs::plain): allocated once per (op, source), grown on demand
+static float* wg_plain_slabs(Model* m, const Op& o, int s, size_t floats) {
+    IgPlan& pl = g_ig[m];
+    const auto key = std::make_pair((const void*)&o, s);
+    auto it = pl.plain.find(key);
+    if (it != pl.plain.end() && it->second.second >= floats) return it->second.first;
+    float* ptr = nullptr;
+    if (m->alloc((void**)&ptr, floats * 4) != DNNCA_OK) return nullptr;
+    pl.plain[key] = std::make_pair(ptr, floats);
+    return ptr;
+}
+static bool wg_plain_on() {
+    static const bool off = getenv("DNNCA_NO_WG_PLAIN") != nullptr;          // keep the float atomics (A/B)
+    return !off;
 }
 
 static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
@@ -2483,7 +2557,10 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
         const int combos = (cs / (16 * mw)) * (CO / (16 * nn));
         return (256 + combos - 1) / combos;
     };
-    if (wgrad2_path(CA) && (!CB || wgrad2_path(CB)) && n_w + CO <= WG_SLAB_FLOATS && wgrad2_psplit(CA) > 32 &&
+    // (the split-bf16 kernel in plain mode needs no buckets: every block stores into its own slab)
+    static const bool x3_wgrad_off = getenv("DNNCA_NO_X3_WGRAD") != nullptr;
+    const bool plain3 = ig3x_enabled(m) && !x3_wgrad_off && wg_plain_on();
+    if (!plain3 && wgrad2_path(CA) && (!CB || wgrad2_path(CB)) && n_w + CO <= WG_SLAB_FLOATS && wgrad2_psplit(CA) > 32 &&
         !getenv("DNNCA_NO_WG_BUCKETS")) {
         if (!pl.wg_slabs && !m->dry && m->alloc((void**)&pl.wg_slabs, (size_t)WG_BUCKETS * WG_SLAB_FLOATS * 4) != DNNCA_OK) pl.wg_slabs = nullptr;
         bucketed = m->dry || pl.wg_slabs != nullptr;          // the dry run lists the launches of the real one
@@ -2515,6 +2592,32 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             w.psplit = psplit;
             dim3 grid(psplit, w.cs / ig::CK, CO / (16 * nn));
             const double bb = (out_bytes + in_bytes) / (CB ? 2 : 1), ff = flops / (CB ? 2 : 1);
+            // plain mode (WgArgs::plain) for a launch of `ps` pixel-split blocks per channel-block pair: slabs instead of the gradient
+            const int n_ws = 9 * w.cs * CO, pstride = (n_ws + CO + 3) / 4 * 4;
+            auto go_plain = [&](int ps) {
+                if (!wg_plain_on() || bucketed) return false;
+                float* slabs = m->dry ? nullptr : wg_plain_slabs(m, o, s, (size_t)ps * pstride);
+                if (!m->dry && !slabs) return false;
+                w.dw = slabs;
+                w.dbias = s == 0 ? slabs + n_ws : nullptr;
+                w.cin_total = w.cs;
+                w.ci_off = 0;
+                w.nbuckets = 1;
+                w.bucket_stride = pstride;
+                w.plain = 1;
+                return true;
+            };
+            auto fold_plain = [&](int ps) {
+                const int n_b = s == 0 ? CO : 0;
+                if (n_ws + n_b >= 32768)
+                    LAUNCH(m, "wg_fold", 4.0 * ps * (n_ws + n_b), 0,
+                           hipLaunchKernelGGL(ig::k_wg_fold_plain<1>, dim3((n_ws + n_b + 1023) / 1024), dim3(256), 0, m->stream, w.dw, ps, pstride, w.cs,
+                                              CO, CA + CB, s == 0 ? 0 : CA, m->g + o.w_off, m->g + o.b_off, n_b));
+                else
+                    LAUNCH(m, "wg_fold", 4.0 * ps * (n_ws + n_b), 0,
+                           hipLaunchKernelGGL(ig::k_wg_fold_plain<16>, dim3((n_ws + n_b + 63) / 64), dim3(256), 0, m->stream, w.dw, ps, pstride, w.cs,
+                                              CO, CA + CB, s == 0 ? 0 : CA, m->g + o.w_off, m->g + o.b_off, n_b));
+            };
             if (use_bf16(m, o) && CO % 64 == 0 && w.cs % 64 == 0) {
                 const int combos64 = (w.cs / 64) * (CO / 64);
                 int ps = (256 + combos64 - 1) / combos64;
@@ -2524,8 +2627,10 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
                 const bool xh = (s == 0 ? o.inA.d.h : o.inB.d.h) != 0, gh = o.out.g.h != 0;
                 static const int narrow = getenv("DNNCA_WGRAD64_NARROW") != nullptr;          // tuning aid
                 if (xh && gh && !narrow && (double)B * w.H * w.W * (w.cs > CO ? w.cs : CO) * 2.0 < 2.0e9) {         // eight waves per block (bf16-stored operands, 32-bit byte offsets)
-                    m->set_variant("w8");
+                    const bool plain = go_plain(w.psplit);
+                    m->set_variant(plain ? "w8p" : "w8");
                     LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL(igb::k_igb_wgrad64w<2>, g64, dim3(512), 0, m->stream, w));
+                    if (plain) fold_plain(w.psplit);
                     continue;
                 }
     #define WG64(XH, GH) LAUNCH(m, "igb_wgrad64", bb, ff, hipLaunchKernelGGL((igb::k_igb_wgrad64<XH, GH>), g64, dim3(256), 0, m->stream, w))
@@ -2536,7 +2641,16 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             } else if (!use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (w.cs > CO ? w.cs : CO) * 4.0 < 2.0e9 &&
                        !getenv("DNNCA_WGRAD1")) {
                 // fp32 by three bf16 planes on the bf16 matrix pipe (kernels_ig3x.hip), unless switched off
-                if (ig3x_wgrad_launch(m, w, CO, "ig3x_wgrad", bb, ff)) continue;
+                {
+                    const int ps3 = ig3x_wgrad_psplit(m, w, CO);
+                    if (ps3 > 0) {
+                        const bool plain = go_plain(ps3);
+                        if (ig3x_wgrad_launch(m, w, CO, "ig3x_wgrad", bb, ff)) {
+                            if (plain) fold_plain(ps3);
+                            continue;
+                        }
+                    }
+                }
                 const int mw = w.cs % 64 == 0 ? 4 : (w.cs % 32 == 0 ? 2 : 1);
                 const int tm = (4 / mw) < (4 / nn) ? (4 / mw) : (4 / nn);
                 const int nt2 = tiles_x * ((o.out.d.H + 8 * tm - 1) / (8 * tm)) * B;
