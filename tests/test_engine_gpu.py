@@ -277,6 +277,26 @@ def test_dense_configs_at_real_widths_against_oracle(gpu, arch, C, opts, B, size
     n_bn = sum(1 for n, _ in Hp.tensor_slices(spec) if n.endswith('.gamma'))
     n_apply = launches.count('bn_apply') + launches.count('bn_apply_pool')
     assert n_apply <= n_bn // 2, (n_apply, n_bn)
+    # inference at the same widths (engine.py:198-203: evaluate runs training=False): the elision is decided regardless of `training`,
+    # so the convs then apply the MOVING-statistics coefficients while they stage their input.  The step above (learning rate 0) has
+    # left the weights alone and updated the moving statistics: logits against oracle.predict on exactly that state, masks at 0.5 /
+    # 0.8 bit-exact wherever the oracle logit is farther from the threshold than the logit tolerance; the launches of that forward
+    # pass (HIP-event profile) must show the elided apply passes missing.
+    p_after = dict(params, **state)
+    prob_ref, logit_ref = O.predict(spec, p_after, x.astype(np.float64))
+    m.profile_reset()
+    m.profile_enable(1)
+    prob, logits = m.forward(x, training=False, return_logits=True)
+    eval_launches = {r[0]: r[1] for r in m.profile()}
+    m.profile_enable(0)
+    tol = 2e-4 * max(1.0, float(np.abs(logit_ref).max()))
+    assert np.abs(logits - logit_ref).max() <= tol, np.abs(logits - logit_ref).max()
+    assert np.abs(prob - prob_ref).max() <= tol
+    for thr in (0.5, 0.8):
+        decided = np.abs(logit_ref - np.log(thr / (1 - thr))) > tol
+        assert np.array_equal((prob > thr)[decided], (prob_ref > thr)[decided]), 'mask flip away from the threshold'
+    n_apply_eval = eval_launches.get('bn_apply', 0) + eval_launches.get('bn_apply_pool', 0)
+    assert any(k.startswith('ig3x_conv_fwd') for k in eval_launches) and n_apply_eval <= n_bn // 2, eval_launches
     Hp.record_oracle_plan(m, 'test_dense_configs_at_real_widths_against_oracle')
     m.close()
 
@@ -445,7 +465,8 @@ def _per_tensor_cosine(spec, g, gref):
 
 
 @pytest.mark.parametrize('nw', [4, 8])
-@pytest.mark.parametrize('f0,S,B,bn,n_down', [(64, 24, 2, 0, 2), (64, 16, 2, 0, 2), (32, 24, 2, 0, 2), (64, 24, 2, 1, 1)])
+@pytest.mark.parametrize('f0,S,B,bn,n_down', [(64, 24, 2, 0, 2), (64, 16, 2, 0, 2), (32, 24, 2, 0, 2), (64, 24, 2, 1, 1), (64, 16, 2, 1, 1),
+                                              (64, 16, 2, 1, 2), (32, 24, 2, 1, 2)])
 def test_bf16_kernels_against_bf16_emulating_oracle(gpu, f0, S, B, bn, n_down, nw):
     """dtype bf16 (BASELINE configs[2]): the implicit-GEMM kernels round their operands to bf16 while staging and accumulate in
     fp32; the oracle is made to do exactly that (tests/bf16_emul_case.py), so the comparison isolates the kernels' indexing
@@ -458,7 +479,15 @@ def test_bf16_kernels_against_bf16_emulating_oracle(gpu, f0, S, B, bn, n_down, n
     relative and flips a quarter of THOSE roundings.  So the agreement is only far below the bf16 noise itself (per tensor
     4e-2 .. 1e-1 between the emulating and the exact oracle on these networks) while few such cones exist -- at small
     images: measured per-tensor 1.4e-3 .. 5.2e-3 here, identical for NW = 4 and 8 (profiles/r02_bf16_emulation_evidence.txt;
-    at 40 x 40 it is 5e-2 already, with BatchNorm over two levels 3e-1).  Bound: 2e-2 per tensor, every tensor."""
+    at 40 x 40 it is 5e-2 already, with BatchNorm over two levels 3e-1).  Bound: 2e-2 per tensor, every tensor.
+
+    Round 4: a second size for the bf16-STORED operand kernels (BatchNorm, one level, S = 16: measured 1.4e-2 per tensor, same bound), and
+    BatchNorm over TWO levels at f0 = 64 / S = 16 and f0 = 32 / S = 24 (the launch mix of three resolutions with stored-bf16 tensors
+    between them).  There the rounding cones cover the image: measured per-tensor error 8e-2 .. 1.4e-1 in the median, 0.22 .. 0.44 at
+    worst, err_l2 0.08 .. 0.14 -- the level of bf16 noise itself (emulating against exact oracle: 4e-2 .. 1e-1 per tensor on the
+    one-level networks), identical for NW = 4 and 8 to seven digits.  Those two cases are held to median <= 0.25, err_l2 <= 0.25,
+    worst tensor <= 0.8: a mis-indexed or dropped tensor is off by 1.0 and takes err_l2 with it; what they pin beyond that is that
+    both wave variants agree bit-for-bit in the loss and that every launch of the mix runs.  The tight bound stays with the cases above."""
     import json
     import subprocess
     import sys
@@ -469,13 +498,20 @@ def test_bf16_kernels_against_bf16_emulating_oracle(gpu, f0, S, B, bn, n_down, n
     o = json.loads(r.stdout.strip().splitlines()[-1])
     if not bn:      # (with BatchNorm the inference logits use the moving statistics: not the oracle's training logits)
         assert o['dl_max'] <= 2e-3 and o['dl_median'] <= 5e-4, (o['dl_max'], o['dl_median'])
-    assert abs(o['loss'] - o['loss_ref']) <= 1e-3 * max(1.0, abs(o['loss_ref']))
-    bad = {n: e for n, e in o['per_tensor'].items() if not e <= 2e-2}
-    assert not bad and o['err_l2'] <= 1e-2, (o['err_l2'], bad)
+    assert abs(o['loss'] - o['loss_ref']) <= (2e-3 if bn and n_down > 1 else 1e-3) * max(1.0, abs(o['loss_ref']))
+    if bn and n_down > 1:      # two BatchNorm levels: bf16 rounding is chaotic there (docstring)
+        pt = sorted(o['per_tensor'].values())
+        assert pt[len(pt) // 2] <= 0.25 and pt[-1] <= 0.8 and o['err_l2'] <= 0.25, (pt[len(pt) // 2], pt[-1], o['err_l2'])
+    else:
+        bad = {n: e for n, e in o['per_tensor'].items() if not e <= 2e-2}
+        assert not bad and o['err_l2'] <= 1e-2, (o['err_l2'], bad)
     plan = set(o['plan'])
     Hp.record_oracle_plan(plan, 'test_bf16_kernels_against_bf16_emulating_oracle')
     suffix = '_w%d' % nw
-    assert {'igb_conv_fwd' + suffix, 'igb_conv_dgrad' + suffix + ('_a16' if bn else '')} <= plan, plan   # the variant under test ran
+    if bn and f0 == 32:        # (mixed 32 / 64-channel network: only its 64-channel level stores bf16 tensors)
+        assert any(n.startswith('igb_conv_fwd' + suffix) for n in plan) and any(n.startswith('igb_conv_dgrad' + suffix) for n in plan), plan
+    else:
+        assert {'igb_conv_fwd' + suffix, 'igb_conv_dgrad' + suffix + ('_a16' if bn else '')} <= plan, plan   # the variant under test ran
     assert not any(n.startswith('igb_conv') and n.endswith('_w%d' % (12 - nw)) for n in plan)
     if f0 == 64 and not bn:
         assert {'igb_wgrad64', 'igb_tconv_fwd', 'igb_tconv_wgrad', 'igb_tconv_dgrad', 'igb_wgrad'} <= plan
