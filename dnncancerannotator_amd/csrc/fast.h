@@ -25,6 +25,7 @@ bool fast_first3_fwd(Model* m, int B, Op& c1, Op& c2, Op& pool, float* y0, unsig
 bool fast_up3_fwd(Model* m, int B, size_t oi);     // last decoder block: transposed conv + two-source conv forward in one column-strip launch
 bool fast_head_in_conv_possible(Model* m);      // would fast_conv_fwd_head take the conv that feeds the head?
 bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid, int* consumed = nullptr);
+bool fused_up2_fwd(Model* m, int B, size_t oi, bool store_mid);     // the two convs of a decoder block whose transposed conv has already run: ops[oi], ops[oi + 1]
 // kernels_fused_bwd.hip: the whole BACKWARD of a Downsample / Upsample block of configs/unet.yaml (6- and 12-channel levels) in one
 // launch; `oi` is the block's LAST op (the max-pool / the second conv): ops[oi - 2 .. oi] are consumed when these return true
 bool fused_down_bwd(Model* m, int B, size_t oi);
@@ -57,6 +58,14 @@ bool fast_bn_bwd(Model* m, int B, Op& o);
 bool fast_pool_into_bn(Model* m, Op& pool, Op& bn);      // the pool's backward rides in the backward passes of the BatchNorm in front of it
 bool fast_bn_supported(const Model* m, const Op& o);
 void fast_plan_masks(Model* m);
+// Path-selecting switches of the dense kernels (tuning aids / A-B arms), read ONCE per process at their first use: the plan made at
+// model creation (which BatchNorm apply passes are elided, ig_norm_on_load_ok) and every later launch decision must see the same
+// values -- a conv must never read a normalised tensor that was never written.  (The per-model switches DNNCA_NO_HALF* are read when
+// a model is built; the unet.yaml fusion switches are read per call: each of those paths falls back on the launches it replaced.)
+struct DenseSwitches {
+    bool igconv1, wgrad1, no_bn_fusion, no_pool_stats, no_wg_buckets, tcwgrad1;
+};
+const DenseSwitches& dense_switches();
 // implicit-GEMM MFMA path for channel counts that are multiples of 16 (kernels_igemm.hip)
 bool ig_conv_supported(const Model* m, const Op& o);
 int ig_prepare(Model* m);

@@ -194,7 +194,7 @@ bool fast_first_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op*
     first::Args a = first_args(m, B, o);
     a.alpha = o.alpha;
     const int blocks = a.ntiles < 4096 ? a.ntiles : 4096;
-    if (bn_next && !getenv("DNNCA_NO_BN_FUSION"))       // the BatchNorm behind this conv takes its batch statistics from here
+    if (bn_next && !dense_switches().no_bn_fusion)       // the BatchNorm behind this conv takes its batch statistics from here
         (void)bn_self_fold_args(m, *bn_next, B, &a.bnf);
     LAUNCH(m, "first_fwd", bytes, flops, hipLaunchKernelGGL(first::k_first_fwd, dim3(blocks), dim3(256), 0, m->stream, a));
     return true;

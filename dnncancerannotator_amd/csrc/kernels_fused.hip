@@ -225,6 +225,7 @@ struct UpArgs {
     const float* bmat1;
     const float* bias0;
     const float* bias1;
+    const float* upin;       // NOTC: the transposed conv's output [B, H, W, F], computed by an earlier launch (the 12-channel block's riding tconv)
     float* up;               // transposed conv output [B, H, W, F]   (nullptr: not stored)
     float* y0;               // conv0 output                          (nullptr: not stored)
     float* y1;               // conv1 output
@@ -236,7 +237,10 @@ struct UpArgs {
     float* nup;              // [B, 2H, 2W, NF]
 };
 
-template <int CIN, int F, int TW, int TH, int NT, int MINW, int NF = 0>
+// NOTC: the block WITHOUT its transposed conv -- conv0 over [up | skip] and conv1 only; the up-sampled tensor comes from memory (upin:
+// the previous decoder block's launch computed it in its epilogue, NF there).  The up-sampled tile is then staged like the skip tile,
+// both are committed right after conv0, and t2 gets LDS of its own (with the transposed conv inside, t2 aliases the up-sampled tile).
+template <int CIN, int F, int TW, int TH, int NT, int MINW, int NF = 0, bool NOTC = false>
 __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
     constexpr int NW = NT / 64;
     constexpr int G = 12 / F, RG = even_up(cdiv(TW + 5, G)), RG2 = TW / G, MPR = RG2 / 16;
@@ -257,24 +261,35 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
     static_assert(STL::LEAD == LLEAD, "low tile lead");
     constexpr int KS0 = CV0::KS, KS1 = CV1::KS;
     static_assert(TH * T2::LS <= TU::N, "t2 aliases the up-sampled tile");
-    __shared__ float4 lds4[LN / 4 + 2 * TU::N4 + T1::N4];
+    constexpr int T2N = up4(T2::LEAD + TH * T2::LS + 8);
+    constexpr int R0 = NOTC ? T2N : LN;                   // first LDS region: the low-resolution tile, or (NOTC) t2
+    __shared__ float4 lds4[R0 / 4 + 2 * TU::N4 + T1::N4];
     float* tlow = reinterpret_cast<float*>(lds4);
-    float* tup = tlow + LN;
+    float* tup = tlow + R0;
     float* tskip = tup + TU::N;
     float* t1 = tskip + TU::N;
-    float* t2 = tup;                                      // dead by the time conv1 runs: conv0 has consumed tup
+    float* t2 = NOTC ? tlow : tup;                        // (tup is dead by the time conv1 runs: conv0 has consumed it)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
     const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
 
     STL stl;
-    STS sts;
+    STS sts, stu;
     int tile = blockIdx.x;
     int b, x0, y0;
+    auto issue_inputs = [&]() {
+        if constexpr (NOTC) stu.issue(p.upin, b, y0, x0, p.H, p.W, tid);
+        else stl.issue(p.low, b, y0 >> 1, x0 >> 1, p.H >> 1, p.W >> 1, tid);
+        sts.issue(p.skip, b, y0, x0, p.H, p.W, tid);
+    };
+    auto commit_inputs = [&]() {
+        if constexpr (NOTC) stu.commit(tup, tid);
+        else stl.commit(tlow, tid);
+        sts.commit(tskip, tid);
+    };
     if (tile < ntiles) {
         decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
-        stl.issue(p.low, b, y0 >> 1, x0 >> 1, p.H >> 1, p.W >> 1, tid);
-        sts.issue(p.skip, b, y0, x0, p.H, p.W, tid);
+        issue_inputs();
     }
     float breg0[KS0], breg1[KS1];
     load_breg<KS0>(breg0, p.bmat0, lane);
@@ -290,12 +305,12 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
         const int rr = nb * 16 + (lane & 15);
         const bool rv = rr < 4 * F;
         const int ae = rv ? rr / F : 0, cc = rv ? rr - ae * F : 0;
-        tbias[nb] = rv ? p.bt[cc] : 0.f;
+        tbias[nb] = (!NOTC && rv) ? p.bt[cc] : 0.f;          // (NOTC: no transposed conv in this launch, wt / bt are null)
         toff[nb] = rv ? (ae >> 1) * TU::LS + (ae & 1) * F + cc : -1;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             const int ci = 4 * k + (lane >> 4);
-            tw[nb][k] = (rv && ci < CIN) ? p.wt[rr * CIN + ci] : 0.f;
+            tw[nb][k] = (!NOTC && rv && ci < CIN) ? p.wt[rr * CIN + ci] : 0.f;
         }
     }
 
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
             for (int k = 0; k < KT2; ++k) tw2[a2][k] = nv ? p.nwt[(a2 * 2 * NF + n) * F + 4 * k + (lane >> 4)] : 0.f;
     }
 
-    for (int i = tid; i < LN / 4 + 2 * TU::N4 + T1::N4; i += NT) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < R0 / 4 + 2 * TU::N4 + T1::N4; i += NT) lds4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pin_breg<KS0>(breg0);
     pin_breg<KS1>(breg1);
@@ -337,13 +352,11 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
     // right after conv0 (the last reader of tlow / tskip), before this tile's stores are issued
     int cb = b, cx0 = x0, cy0 = y0;
     if (tile < ntiles) {
-        stl.commit(tlow, tid);
-        sts.commit(tskip, tid);
+        commit_inputs();
         tile += gridDim.x;
         if (tile < ntiles) {
             decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
-            stl.issue(p.low, b, y0 >> 1, x0 >> 1, p.H >> 1, p.W >> 1, tid);
-            sts.issue(p.skip, b, y0, x0, p.H, p.W, tid);
+            issue_inputs();
         }
         lds_barrier();
     } else {
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
         // Conv2DTranspose(k = s = 2, no activation): up[2i + a][2j + e][co] = bias[co] + sum_ci low[i][j][ci] W[a][e][co][ci]
         // for every pixel of the (TH + 4) x (TW + 4) tile, zeros outside the image
 #pragma unroll 1
-        for (int mt = wave; mt < NMTL; mt += NW) {
+        for (int mt = NOTC ? NMTL : wave; mt < NMTL; mt += NW) {          // (NOTC: the up-sampled tile was staged)
             const float* ap = tlow + LLEAD + (mt * 16 + (lane & 15)) * CIN + (lane >> 4);
             f32x4 tacc[NB];
 #pragma unroll
@@ -392,16 +405,14 @@ __global__ __launch_bounds__(NT, MINW) void k_fz_up(UpArgs p) {
         const bool more = tile < ntiles;
         const int nb_ = b, nx0 = x0, ny0 = y0;
         if (more) {
-            stl.commit(tlow, tid);
-            sts.commit(tskip, tid);
+            commit_inputs();
             tile += gridDim.x;
             if (tile < ntiles) {
                 decode_tile(tile, ntiles, xcd_map, p.tiles_x, p.tiles_y, TW, TH, b, x0, y0);
-                stl.issue(p.low, b, y0 >> 1, x0 >> 1, p.H >> 1, p.W >> 1, tid);
-                sts.issue(p.skip, b, y0, x0, p.H, p.W, tid);
+                issue_inputs();
             }
         }
-        if (p.up) store_interior<F, G, RG, TH + 4, 2, TW, TH, NT>(tup, p.up, cb, cy0, cx0, p.H, p.W, tid);
+        if (!NOTC && p.up) store_interior<F, G, RG, TH + 4, 2, TW, TH, NT>(tup, p.up, cb, cy0, cx0, p.H, p.W, tid);
         if (edge) zero_ring<F, G, RG, TH + 2, TW + 2, T1::LEAD, NT>(t1, edge, tid);
         lds_barrier();                                    // t2 (= tup) may be overwritten; the ring is in place
         FZ_STAMP(3);
@@ -618,6 +629,43 @@ bool fused_up_fwd(Model* m, int B, size_t oi, bool store_mid, int* consumed) {
     X(12, 12, 32, 8, 512, 2) X(12, 6, 64, 8, 512, 2) X(6, 3, 128, 8, 512, 4)
 #undef X
     return false;
+}
+
+// ops[oi], ops[oi + 1] = conv3x3([up | skip] -> F), conv3x3(F -> F) of an Upsample block (components.py:162-165) whose transposed conv has
+// already run (it rode in the previous block's launch, fz_up_tc_12_12): the rest of the block in one launch (k_fz_up<..., NOTC>).
+bool fused_up2_fwd(Model* m, int B, size_t oi, bool store_mid) {
+    // OFF by default.  Measured on MI355X (round 4, bench.py --steps 50, same box): fz_up2_6 34.4 us against pgfwd_6x2_6 + pgfwd_6x1_6
+    // 21.5 + 14.3 us under event brackets, the step 0.4059 ms (14 launches) against 0.4034 ms (15): the launch it saves is paid back by
+    // the halo recompute of conv0 on the fp32 matrix pipe (+29 % MFMAs on a 64 x 8 tile), as round 2 found for the whole block.
+    // DNNCA_FZ_UP2=1 enables it (read per call: the test flips it).
+    if (!getenv("DNNCA_FZ_UP2") || !fz_enabled() || (m->desc.flags & 1) || m->desc.dtype != DNNCA_F32) return false;
+    if (oi + 1 >= m->ops.size()) return false;
+    Op &c0 = m->ops[oi], &c1 = m->ops[oi + 1];
+    if (c0.type != OP_CONV || c1.type != OP_CONV || c0.k != 3 || c1.k != 3) return false;
+    if (!c0.inB.d.C || c1.inB.d.C || c1.inA.d.p != c0.out.d.p) return false;
+    if (!dense(c0.inA.d) || !dense(c0.inB.d) || !dense(c0.out.d) || !dense(c1.out.d)) return false;
+    const int F = c0.inA.d.C, H = c0.out.d.H, W = c0.out.d.W;
+    if (F != 6 || c0.inB.d.C != F || c0.out.d.C != F || c1.out.d.C != F || c0.inB.d.H != H || c0.inB.d.W != W) return false;
+    if (W % 64 || H % 8) return false;
+    if (c0.src_bn[0] >= 0 || c0.src_bn[1] >= 0) return false;
+    const float *b0 = fast_conv_bmat(m, c0), *b1 = fast_conv_bmat(m, c1);
+    if (!b0 || !b1) return false;
+    fz::UpArgs a{};
+    a.upin = c0.inA.d.p; a.skip = c0.inB.d.p;
+    a.bmat0 = b0; a.bmat1 = b1;
+    a.bias0 = m->p + c0.b_off; a.bias1 = m->p + c1.b_off;
+    a.y0 = store_mid ? c0.out.d.p : nullptr;
+    a.y1 = c1.out.d.p;
+    a.B = B; a.H = H; a.W = W;
+    a.alpha0 = c0.alpha; a.alpha1 = c1.alpha;
+    a.tiles_x = W / 64; a.tiles_y = H / 8;
+    const double bytes = 4.0 * B * H * W * (2 * F + F + F + F);        // conv0 (2 in + out) + conv1 (in + out)
+    const double flops = 2.0 * B * H * W * 9.0 * (2 * F * F + F * F);
+    const int ntiles = a.tiles_x * a.tiles_y * B;
+    static const int fit = fz_resident(fz::k_fz_up<12, 6, 64, 8, 512, 2, 0, true>, 512);
+    const int g = ntiles < fit ? ntiles : fit;
+    LAUNCH(m, "fz_up2_6", bytes, flops, hipLaunchKernelGGL((fz::k_fz_up<12, 6, 64, 8, 512, 2, 0, true>), dim3(g), dim3(512), 0, m->stream, a));
+    return true;
 }
 
 }  // namespace dnnca

@@ -2207,6 +2207,13 @@ static bool wg_plain_on() {
     return !off;
 }
 
+const DenseSwitches& dense_switches() {
+    static const DenseSwitches sw = {getenv("DNNCA_IGCONV1") != nullptr, getenv("DNNCA_WGRAD1") != nullptr, getenv("DNNCA_NO_BN_FUSION") != nullptr,
+                                     getenv("DNNCA_NO_POOL_STATS") != nullptr, getenv("DNNCA_NO_WG_BUCKETS") != nullptr,
+                                     getenv("DNNCA_TCWGRAD1") != nullptr};
+    return sw;
+}
+
 static inline bool dense(const View& v) { return v.C == 0 || v.ps == v.C; }
 
 bool ig_conv_supported(const Model* m, const Op& o) {
@@ -2389,7 +2396,7 @@ static bool conv3_path(const ig::ConvArgs& a, int cout, bool bf16) {
     const bool fits = (double)a.B * a.H * a.W * cmax * 4.0 < 2.0e9 && 9.0 * cout * (a.c_src0 + a.c_src1) * 4.0 < 2.0e9 &&
                       (double)a.B * a.H * a.W * dmax < 4.0e9;
     if (bf16) return fits && cout % 64 == 0 && a.c_src0 % 32 == 0 && a.c_src1 % 32 == 0 && a.n_dst0 % 64 == 0;
-    return fits && !getenv("DNNCA_IGCONV1");
+    return fits && !dense_switches().igconv1;
 }
 // waves per block of igb::k_igb_conv3: 8 (32 x 16-pixel tiles, two waves per SIMD) once that still gives every CU a unit
 static int igb_waves(const ig::ConvArgs& a, int cout) {
@@ -2482,7 +2489,7 @@ static void launch_igb(Model* m, const ig::ConvArgs& a, const igb::bf16_t* w16, 
 // the launch condition of k_ig_wgrad2 (second-generation fp32 weight gradient) for a source of cs channels
 static bool wgrad2_ok(const Model* m, const Op& o, int B, int cs) {
     const int CO = o.out.d.C;
-    return !use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (cs > CO ? cs : CO) * 4.0 < 2.0e9 && !getenv("DNNCA_WGRAD1");
+    return !use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (cs > CO ? cs : CO) * 4.0 < 2.0e9 && !dense_switches().wgrad1;
 }
 
 static ig::ConvArgs conv_fwd_geometry(int B, const Op& o) {
@@ -2526,7 +2533,7 @@ bool ig_conv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_next
     a.alpha = o.alpha;
     a.src_half = o.inA.d.h;          // ig_plan_half keeps both sources of a conv in the same format
     a.dst_half = o.out.d.h;
-    if (bn_next && !getenv("DNNCA_NO_BN_FUSION") && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
+    if (bn_next && !dense_switches().no_bn_fusion && conv3_path(a, o.out.d.C, use_bf16(m, o))) {
         // the BatchNorm behind this conv takes its batch statistics (and coefficients) from the conv's epilogue
         (void)bn_self_fold_args(m, *bn_next, B, &a.bnf);
     }
@@ -2561,7 +2568,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
     static const bool x3_wgrad_off = getenv("DNNCA_NO_X3_WGRAD") != nullptr;
     const bool plain3 = ig3x_enabled(m) && !x3_wgrad_off && wg_plain_on();
     if (!plain3 && wgrad2_path(CA) && (!CB || wgrad2_path(CB)) && n_w + CO <= WG_SLAB_FLOATS && wgrad2_psplit(CA) > 32 &&
-        !getenv("DNNCA_NO_WG_BUCKETS")) {
+        !dense_switches().no_wg_buckets) {
         if (!pl.wg_slabs && !m->dry && m->alloc((void**)&pl.wg_slabs, (size_t)WG_BUCKETS * WG_SLAB_FLOATS * 4) != DNNCA_OK) pl.wg_slabs = nullptr;
         bucketed = m->dry || pl.wg_slabs != nullptr;          // the dry run lists the launches of the real one
     }
@@ -2639,7 +2646,7 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
                 else { if (gh) WG64(false, true); else WG64(false, false); }
     #undef WG64
             } else if (!use_bf16(m, o) && (double)B * o.out.d.H * o.out.d.W * (w.cs > CO ? w.cs : CO) * 4.0 < 2.0e9 &&
-                       !getenv("DNNCA_WGRAD1")) {
+                       !dense_switches().wgrad1) {
                 // fp32 by three bf16 planes on the bf16 matrix pipe (kernels_ig3x.hip), unless switched off
                 {
                     const int ps3 = ig3x_wgrad_psplit(m, w, CO);
@@ -2741,7 +2748,7 @@ bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_nex
     ig::TcArgs a = tc_args(m, B, o);
     if (use_bf16_tc(m, o)) {
         IgPlan& pl = g_ig[m];
-        if (bn_next && !getenv("DNNCA_NO_BN_FUSION"))       // batch statistics of the BatchNorm behind it ride in the epilogue
+        if (bn_next && !dense_switches().no_bn_fusion)       // batch statistics of the BatchNorm behind it ride in the epilogue
             (void)bn_self_fold_args(m, *bn_next, B, &a.bnf);
         const dim3 grid((a.npix + 127) / 128, a.cout / 64);
         m->set_variant("h%d", (int)(o.inA.d.h != 0));
@@ -2788,7 +2795,7 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
     }
     hipStream_t main_stream = m->stream;
     const bool side = m->wg_side_begin();
-    if ((double)a.npix * 4.0 * a.cout * 4.0 < 2.0e9 && (double)a.npix * a.cin * 4.0 < 2.0e9 && !getenv("DNNCA_TCWGRAD1")) {
+    if ((double)a.npix * 4.0 * a.cout * 4.0 < 2.0e9 && (double)a.npix * a.cin * 4.0 < 2.0e9 && !dense_switches().tcwgrad1) {
         // second generation: (16 mw x 16 nn) channel tiles x 4 parities, 32-bit byte offsets
         const int mw = a.cout % 64 == 0 ? 4 : (a.cout % 32 == 0 ? 2 : 1), nn = pick_nn(a.cin);
         const int tm = (4 / mw) < (4 / nn) ? (4 / mw) : (4 / nn);

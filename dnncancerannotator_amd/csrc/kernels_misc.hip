@@ -992,7 +992,7 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
         const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
         unsigned* ix = reinterpret_cast<unsigned*>(pool->pool_idx);
         BnSelfFold pf{};          // batch statistics of the pooled tensor for the BatchNorm behind the pool
-        if (pool_bn && training && !getenv("DNNCA_NO_BN_FUSION") && !getenv("DNNCA_NO_POOL_STATS")) (void)bn_self_fold_args(m, *pool_bn, B, &pf);
+        if (pool_bn && training && !dense_switches().no_bn_fusion && !dense_switches().no_pool_stats) (void)bn_self_fold_args(m, *pool_bn, B, &pf);
         // does anybody but the pool read the normalised tensor?  (out_readers: model.hip; -1 = a reader it does not understand)
         bool write_y = o.out_readers.empty();
         for (int r : o.out_readers) write_y = write_y || r < 0 || &m->ops[r] != pool;

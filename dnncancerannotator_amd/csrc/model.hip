@@ -507,6 +507,10 @@ int Model::forward(const float* x_dev, int B, bool training) {
                     oi += 2;
                     break;
                 }
+                if (!generic && o.inB.d.C && fused_up2_fwd(this, B, oi, training)) {      // the two convs of a decoder block (its transposed conv rode earlier)
+                    oi += 1;
+                    break;
+                }
                 Op* pool = (!generic && oi + 1 < ops.size() && fast_pool_fusable(this, o, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
                 if (!generic && fast_conv_fwd(this, B, o, bytes + (pool ? 4.0 * nelem(B, pool->out.d) : 0.0), flops, pool)) {
                     pool_done = pool;

@@ -749,7 +749,8 @@ def test_non_square_leaky_l2_tuned_kernels(gpu, arch, C, opts):
 
 
 @pytest.mark.parametrize('B, H, W, strip', [(2, 40, 128, True), (8, 16, 256, True), (2, 40, 128, False), (8, 16, 256, False),
-                                            (3, 24, 200, True), (1, 72, 64, True), (2, 64, 256, True), (2, 64, 256, 'per-layer backward')])
+                                            (3, 24, 200, True), (1, 72, 64, True), (2, 64, 256, True), (2, 64, 256, 'per-layer backward'),
+                                            (2, 64, 256, 'fz_up2')])
 def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypatch, B, H, W, strip):
     """configs/unet.yaml, the vector-ALU kernels of the full-resolution 3-channel level against the float64 oracle, every variable on
     its own scale.  strip: the column-strip kernels (strip_dev.h; strips of 60 columns, row chunks; shapes with partial strips, one
@@ -761,6 +762,10 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
     conv behind them on all three levels (k_pgbwd TCF / TCM) and the 12 -> 6 transposed conv's forward in the fused 12-channel
     decoder block (k_fz_up); by default the 6- and 12-channel blocks' backward passes are the block-fused launches of
     kernels_fused_bwd.hip (k_fzb), so the shape runs a second time with DNNCA_NO_FUSED_BWD for the per-layer TCM kernels."""
+    fz_up2 = strip == 'fz_up2'          # the 256^2-level decoder block's two convs as ONE forward launch (k_fz_up<..., NOTC>; opt-in, DNNCA_FZ_UP2)
+    if fz_up2:
+        monkeypatch.setenv('DNNCA_FZ_UP2', '1')
+        strip = True
     per_layer_bwd = strip == 'per-layer backward'
     if per_layer_bwd:
         monkeypatch.setenv('DNNCA_NO_FUSED_BWD', '1')
@@ -790,6 +795,7 @@ def test_vector_alu_kernels_of_the_3_channel_level_against_oracle(gpu, monkeypat
               {'fzb_up_6', 'fzb_up_12', 'fzb_down_6_12', 'fzb_down_3_6'}
         assert ({'pgbwd_tc_3x2_3', 'fz_up_tc_12_12', 'fz_down_3_6', 'fz_down_6_12', 'pg_fold'} | bwd) <= plan and not any(k.startswith('tconv') for k in plan), plan
         assert per_layer_bwd or not any(k.startswith('pgbwd_') and k != 'pgbwd_tc_3x2_3' for k in plan), plan
+        assert ('fz_up2_6' in plan and 'pgfwd_6x2_6' not in plan) if fz_up2 else ('pgfwd_6x2_6' in plan and 'fz_up2_6' not in plan), plan
     assert ('tail3_3x1_3' if strip else 'bwd3v_3x1_3') in plan, plan
     if 'fz_down_1_3' in plan or 'first3_fwd' in plan:          # the fused first block records the pool's window positions
         assert ('first3_bwd' if strip else 'bwd3v_pool_3x1_3') in plan and 'pgbwd_w_1x1_3' not in plan or not strip, plan
