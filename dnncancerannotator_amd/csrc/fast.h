@@ -85,8 +85,7 @@ namespace ig { struct ConvArgs; struct WgArgs; }
 bool ig3x_enabled(const Model* m);
 int ig3x_prepare(Model* m);
 void ig3x_release(Model* m);
-bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, int nw, const char* name, double bytes,
-                 double flops);
+bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, const char* name, double bytes, double flops);
 bool ig3x_wgrad_launch(Model* m, ig::WgArgs w, int co, const char* name, double bytes, double flops);
 int ig3x_wgrad_psplit(const Model* m, const ig::WgArgs& w, int co);      // pixel-split blocks of that launch; 0: not this path
 bool ig_tconv_supported(const Model* m, const Op& o);

@@ -124,11 +124,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 // tile its 16 stores per lane and unit took longer than the unit's MFMAs.  Same contract otherwise: MODE 0 bias + activation, the
 // batch statistics of the BatchNorm behind the conv (per-lane sums, DPP row sums over the 16 pixels, `red`, bucket adds; bn_dev.h);
 // MODE 1 accumulate / act' mask / two destinations.  fp32 tensors only (the bf16-stored variants belong to dtype bf16).
-template <int NN, int MODE, int NW>
-__device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0, int tile, float* red,
+// WN > 1: the block's channel tile (16 NN WN channels from co0t) is split over WN groups of NWR row-waves: this wave (row group wave %
+// NWR, channel group wave / NWR) holds NN 16-channel tiles from co0t + 16 NN (wave / NWR).
+template <int NN, int MODE, int NWR, int WN = 1>
+__device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0t, int tile, float* red,
                                            const float* bias_lds) {
     constexpr int COT = 16 * NN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all % NWR, wn = wave_all / NWR, m16 = lane & 15, q = lane >> 4;
+    const int co0 = co0t + COT * wn;
     const int which = co0 >= p.n_dst0;
     const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co0 - p.n_dst0 : co0;
     float* dst = p.dst[which];
@@ -191,17 +194,19 @@ __device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)
             for (int i = 0; i < 4; ++i) {
                 const float s1 = row16_sum(bs[j][i]), s2 = row16_sum(bq[j][i]);
                 if (m16 == 0) {
-                    red[wave * (2 * COT) + 16 * j + 4 * q + i] = s1;
-                    red[wave * (2 * COT) + COT + 16 * j + 4 * q + i] = s2;
+                    red[wave_all * (2 * COT) + 16 * j + 4 * q + i] = s1;
+                    red[wave_all * (2 * COT) + COT + 16 * j + 4 * q + i] = s2;
                 }
             }
         lds_barrier();
-        if (tid < 2 * COT) {
+        if (tid < WN * 2 * COT) {          // thread t: channel group t / (2 COT), entry t % (2 COT) of that group's [sums | sums of squares]
+            const int g = tid / (2 * COT), e = tid - g * (2 * COT);
             float a = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) a += red[w * (2 * COT) + tid];
-            const int half = tid >= COT, c = half ? tid - COT : tid;
-            atomicAdd(bn_bucket(p.bnf, tile) + half * cw + cl + c, (double)a);
+            for (int w = 0; w < NWR; ++w) a += red[(g * NWR + w) * (2 * COT) + e];
+            const int half = e >= COT, c = half ? e - COT : e;
+            // (all channel groups of a block go to the same destination: a channel tile never straddles the two destinations)
+            atomicAdd(bn_bucket(p.bnf, tile) + half * cw + (cl - COT * wn) + COT * g + c, (double)a);
         }
     }
 }
@@ -209,19 +214,24 @@ __device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)
 // MODE 0 forward, MODE 1 data gradient (the forward kernel on the flipped / transposed planes).  w3: the conv's plane 0,
 // [9][N channels][K channels] bf16 with K contiguous; planes 1, 2 at + pstride, + 2 pstride elements.
 // NW waves: 4 -> 16 x 16-pixel tiles (one wave per SIMD), 8 -> 32 x 16 (two per SIMD).  Channel tile 16 NN.
-template <int NN, int MODE, int NW>
+// WN = 2 (NW = 8 only): 16 x 16-pixel tiles like NW = 4, the eight waves are 4 row groups x 2 channel halves (8 NN channels... 16 NN / 2 each):
+// two waves per SIMD on layers that have too few 32 x 16 tiles to fill the chip (the 64^2 / 128^2 levels) -- a single wave per SIMD cannot
+// issue v_mfma_f32_16x16x32_bf16 back to back, and its LDS waits and barriers are nobody's cover.
+template <int NN, int MODE, int NW, int WN = 1>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_conv3(ConvArgs p, const bf16_t* __restrict__ w3, unsigned pstride) {
-    constexpr int NT = 64 * NW, TR = 4 * NW, PATCHX = (TR + 2) * (T + 2);
+    static_assert(WN == 1 || (WN == 2 && NW == 8 && NN % 2 == 0), "channel split: eight waves, two halves");
+    constexpr int NWR = NW / WN, NJ = NN / WN;            // row groups of waves; 16-channel tiles per wave
+    constexpr int NT = 64 * NW, TR = 4 * NWR, PATCHX = (TR + 2) * (T + 2);
     constexpr int COT = 16 * NN;
     constexpr int APL = PATCHX * KC;                 // bf16 elements per A plane: [patch pixel][16 channels], 32-byte rows
     constexpr int BPL = 9 * COT * KC;                // per B plane: [tap][channel of the tile][16 K channels]
     constexpr int BOFF = 3 * APL, DUMP = BOFF + 3 * BPL, BUF = DUMP + 64;      // + a dump row for the idle lanes of the last staging element
     __shared__ __attribute__((aligned(16))) bf16_t lds[BUF];
-    __shared__ float bn_red[NW * 2 * COT];           // cross-wave fold of the fused BatchNorm statistics (epilogue_t)
+    __shared__ float bn_red[NW * 2 * 16 * NJ];       // cross-wave fold of the fused BatchNorm statistics (epilogue_t)
     // the bias vector, read by the epilogue through LDS: a global load there queues behind the next item's prefetch (vmcnt retires in
     // order) and cost the epilogue of a 16-channel unit 4 k cycles of waiting (tools/x3_stamps.py)
     __shared__ __attribute__((aligned(16))) float bias_lds[MODE == 0 ? kMaxBias : 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % NWR, wn = (tid >> 6) / NWR;          // row group, channel half
     const int m16 = lane & 15, q = lane >> 4;
     const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
     if (MODE == 0)
@@ -366,10 +376,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
     const bf16_t* a_base = lds + ((4 * wave) * (T + 2) + m16) * KC + 8 * (q & 1);
     const bf16_t* aX = a_base + hA * APL;               // (a0 | a1)
     const bf16_t* aY = a_base + 2 * hA * APL;           // (a0 | a2)
-    const bf16_t* b_base = lds + BOFF + m16 * KC + 8 * (q & 1);
+    const bf16_t* b_base = lds + BOFF + (16 * NJ * wn + m16) * KC + 8 * (q & 1);
     const bf16_t* bP[3] = {b_base, b_base + BPL, b_base + (hA ? 0 : 2 * BPL)};          // (b0 | b0), (b1 | b1), (b2 | b0)
 
-    f32x4 acc[4][NN];
+    f32x4 acc[4][NJ];
     issue_item(next_stage());
     int it = 0;
 #pragma unroll 1
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
             X3STAMP(it, 0);
@@ -394,20 +404,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
             // of the next A set are issued before this step's MFMAs (the compiler's own order put every read right in front of its MFMA
             // behind an lgkmcnt(0): one exposed LDS round trip per step).
             {
-                bf16x8 fa[2][6], fb[2][NN];
+                bf16x8 fa[2][6], fb[2][NJ];
                 auto load_a = [&](bf16x8 (&a)[6], const bf16_t* base, int g) {
 #pragma unroll
                     for (int rr = 0; rr < 6; ++rr) a[rr] = *reinterpret_cast<const bf16x8*>(base + (rr * (T + 2) + g) * KC);
                 };
-                auto load_b = [&](bf16x8 (&b)[NN], int pr, int tap) {
+                auto load_b = [&](bf16x8 (&b)[NJ], int pr, int tap) {
 #pragma unroll
-                    for (int j = 0; j < NN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bP[pr] + (tap * COT + 16 * j) * KC);
+                    for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bP[pr] + (tap * COT + 16 * j) * KC);
                 };
-                auto mfmas = [&](const bf16x8 (&a)[6], const bf16x8 (&b)[NN], int dy) {
+                auto mfmas = [&](const bf16x8 (&a)[6], const bf16x8 (&b)[NJ], int dy) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int j = 0; j < NN; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[r + dy], acc[r][j], 0, 0, 0);      // rows = channels, columns = pixels
+                        for (int j = 0; j < NJ; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[r + dy], acc[r][j], 0, 0, 0);      // rows = channels, columns = pixels
                 };
                 load_a(fa[0], aX, 0);
                 load_b(fb[0], 0, 0);
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
             X3STAMP(it, 5);
         }
         const Unit u = unit_of(k);
-        epilogue_t<NN, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red, bias_lds);
+        epilogue_t<NJ, MODE, NWR, WN>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red, bias_lds);
         X3STAMP(it - 1, 6);
     }
     if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);          // block-uniform; every block gets here
@@ -730,32 +740,45 @@ int ig3x_prepare(Model* m) {
     return DNNCA_OK;
 }
 
-// launches the conv (mode 0 forward / 1 data gradient) described by `a` (tiles_x / tiles_y are set here) on the split-bf16 kernel;
-// false: not this path (the caller goes on to the exact-fp32 kernels)
-bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, int nw, const char* name, double bytes,
-                 double flops) {
+// launches the conv (mode 0 forward / 1 data gradient) described by `a` (tiles_x / tiles_y are set here) on the split-bf16 kernel with
+// channel tiles of 16 nn; false: not this path (the caller goes on to the exact-fp32 kernels).
+// Wave layout: eight waves on 32 x 16-pixel tiles while that gives every CU a unit; else (nn >= 2) eight waves on 16 x 16 tiles, split
+// 4 row groups x 2 channel halves; else four waves on 16 x 16 tiles.  DNNCA_IG_NW=4|8 forces the first / last (tuning aid, tests).
+bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, const char* name, double bytes, double flops) {
     if (!ig3x_enabled(m)) return false;
     Ig3xPlan& pl = g_ig3x[m];
     if (!m->dry && (!pl.wf || !pl.wd)) return false;
     if (a.src_half || a.dst_half || a.dsth[0] || a.dsth[1] || cout > ig3x::kMaxBias) return false;          // bf16-stored tensors: dtype bf16 only
     if (9.0 * cout * (a.c_src0 + a.c_src1) + 2.0 * pl.pstride > 1.0e9) return false;          // 32-bit byte offsets into the planes
+    static const int forced = getenv("DNNCA_IG_NW") ? atoi(getenv("DNNCA_IG_NW")) : 0;
+    static const bool no_split = getenv("DNNCA_X3_NO_SPLIT") != nullptr;          // tuning aid
+    const long units8 = (long)((a.W + 15) / 16) * ((a.H + 31) / 32) * a.B * (cout / (16 * nn));
+    int nw = 8, wn = 1;
+    if (forced == 4) nw = 4;
+    else if (forced != 8 && units8 < 256) {
+        if (nn >= 2 && !no_split) wn = 2;
+        else nw = 4;
+    }
+    const int rows = 4 * (nw / wn);
     ig::ConvArgs a2 = a;
     a2.tiles_x = (a.W + ig3x::T - 1) / ig3x::T;
-    a2.tiles_y = (a.H + 4 * nw - 1) / (4 * nw);
+    a2.tiles_y = (a.H + rows - 1) / rows;
     const unsigned units = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / (16 * nn)));
     typedef void (*Kern)(ig::ConvArgs, const ig3x::bf16_t*, unsigned);
-    // [mode][nn index][nw index]
-    static const Kern kerns[2][3][2] = {
-        {{ig3x::k_ig3x_conv3<1, 0, 4>, ig3x::k_ig3x_conv3<1, 0, 8>}, {ig3x::k_ig3x_conv3<2, 0, 4>, ig3x::k_ig3x_conv3<2, 0, 8>},
-         {ig3x::k_ig3x_conv3<4, 0, 4>, ig3x::k_ig3x_conv3<4, 0, 8>}},
-        {{ig3x::k_ig3x_conv3<1, 1, 4>, ig3x::k_ig3x_conv3<1, 1, 8>}, {ig3x::k_ig3x_conv3<2, 1, 4>, ig3x::k_ig3x_conv3<2, 1, 8>},
-         {ig3x::k_ig3x_conv3<4, 1, 4>, ig3x::k_ig3x_conv3<4, 1, 8>}}};
-    const int ni = nn == 4 ? 2 : (nn == 2 ? 1 : 0), wi = nw == 8 ? 1 : 0;
-    const Kern kern = kerns[mode ? 1 : 0][ni][wi];
+    // [mode][nn index][layout: 4 waves, 8 waves, 8 waves split]
+    static const Kern kerns[2][3][3] = {
+        {{ig3x::k_ig3x_conv3<1, 0, 4>, ig3x::k_ig3x_conv3<1, 0, 8>, nullptr},
+         {ig3x::k_ig3x_conv3<2, 0, 4>, ig3x::k_ig3x_conv3<2, 0, 8>, ig3x::k_ig3x_conv3<2, 0, 8, 2>},
+         {ig3x::k_ig3x_conv3<4, 0, 4>, ig3x::k_ig3x_conv3<4, 0, 8>, ig3x::k_ig3x_conv3<4, 0, 8, 2>}},
+        {{ig3x::k_ig3x_conv3<1, 1, 4>, ig3x::k_ig3x_conv3<1, 1, 8>, nullptr},
+         {ig3x::k_ig3x_conv3<2, 1, 4>, ig3x::k_ig3x_conv3<2, 1, 8>, ig3x::k_ig3x_conv3<2, 1, 8, 2>},
+         {ig3x::k_ig3x_conv3<4, 1, 4>, ig3x::k_ig3x_conv3<4, 1, 8>, ig3x::k_ig3x_conv3<4, 1, 8, 2>}}};
+    const int ni = nn == 4 ? 2 : (nn == 2 ? 1 : 0), li = wn == 2 ? 2 : (nw == 8 ? 1 : 0);
+    const Kern kern = kerns[mode ? 1 : 0][ni][li];
     // a persistent kernel's grid is the number of blocks that are resident at once: several per CU where LDS and registers allow
     // (a block alternates between committing an item and running its MFMAs; co-resident blocks fill each other's commit phases)
-    static int occ[2][3][2] = {};
-    int& oc = occ[mode ? 1 : 0][ni][wi];
+    static int occ[2][3][3] = {};
+    int& oc = occ[mode ? 1 : 0][ni][li];
     if (oc == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64 * nw, 0) != hipSuccess || nb < 1) nb = 1;
@@ -766,11 +789,10 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
     const unsigned resident = 256u * (unsigned)oc;
     const unsigned g = units < resident ? units : resident;
     const ig3x::bf16_t* w3 = (mode == 0 ? pl.wf : pl.wd) + w_off;
-    m->set_variant("x3n%dw%d", nn, nw);
+    m->set_variant("x3n%dw%d%s", nn, nw, wn == 2 ? "s" : "");
     LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL(kern, dim3(g), dim3(64 * nw), 0, m->stream, a2, w3, pl.pstride));
     return true;
 }
-
 
 // the split-bf16 weight-gradient kernel's shape for one source: channel tiles, wave roles, pixel-split blocks; false: not this path
 struct Wg3Shape { int mw, nn, wn, nj, wk, tyw, ps; };

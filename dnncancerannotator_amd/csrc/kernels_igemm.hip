@@ -2418,14 +2418,6 @@ static int ig_waves(const ig::ConvArgs& a, int cout) {
     return (forced == 8 || units8 >= 256) ? 8 : 4;
 }
 
-// waves per block of ig3x::k_ig3x_conv3: 8 (32 x 16-pixel tiles) once that still gives every CU a unit
-static int ig3x_waves(const ig::ConvArgs& a, int cout, int nn3) {
-    static const int forced = getenv("DNNCA_IG_NW") ? atoi(getenv("DNNCA_IG_NW")) : 0;        // tuning aid: 4 or 8
-    if (forced == 4 || forced == 8) return forced;
-    const long units8 = (long)((a.W + 15) / 16) * ((a.H + 31) / 32) * a.B * (cout / (16 * nn3));
-    return units8 >= 256 ? 8 : 4;
-}
-
 template <int MODE>
 static void launch_ig(Model* m, const ig::ConvArgs& a, size_t w_off, int cout, const char* name, double bytes, double flops) {
     {   // pipelined persistent kernel: channel tile 16 nn3 must divide both destinations; 32-bit byte offsets
@@ -2434,7 +2426,7 @@ static void launch_ig(Model* m, const ig::ConvArgs& a, size_t w_off, int cout, c
             static const int x3_nn_cap = getenv("DNNCA_X3_NN") ? atoi(getenv("DNNCA_X3_NN")) : 4;          // tuning aid: channel tile at most 16 x this
             const int nnx = nn3 > x3_nn_cap && (x3_nn_cap == 1 || x3_nn_cap == 2) ? x3_nn_cap : nn3;
             // fp32 by three bf16 planes on the bf16 matrix pipe (kernels_ig3x.hip), unless switched off
-            if (ig3x_launch(m, MODE, a, w_off, cout, nnx, ig3x_waves(a, cout, nnx), MODE == 0 ? "ig3x_conv_fwd" : "ig3x_conv_dgrad", bytes, flops))
+            if (ig3x_launch(m, MODE, a, w_off, cout, nnx, MODE == 0 ? "ig3x_conv_fwd" : "ig3x_conv_dgrad", bytes, flops))
                 return;
             ig::ConvArgs a2 = a;
             const int nw = ig_waves(a, cout);
