@@ -173,6 +173,11 @@ def time_workload(wname, steps, warmup, ctx, comm, generic=False, repeats=1, hos
         # `roofline_all` / `top_kernels` carry.
         avg_ms = avg_ms_region if wname == 'unet' else avg_ms_alone
         mfma_peak = 2500.0 if wl['dtype'] == 'bf16' else 157.3        # TFLOP/s dense, MI355X_MICROARCH.md:42-43
+
+        def kernel_peak(kname):
+            """MFMA peak a kernel is priced against, in the units its flops are counted in (fp32 multiply-adds x 2).  The ig3x_*
+            kernels (csrc/kernels_ig3x.hip) compute fp32 products as six bf16 products on the bf16 matrix pipe: 2.5 PFLOP/s / 6."""
+            return 2500.0 / 6.0 if kname.startswith('ig3x_') else mfma_peak
         if wname == 'unet':                  # HBM-bound (AI ~ 9 FLOP/B): algorithmic bytes of the launch / its duration
             bound, unit, peak = 'hbm', 'GB/s', HBM_PEAK_GBS
             achieved = bytes_per / (avg_ms * 1e-3) / 1e9
@@ -183,7 +188,6 @@ def time_workload(wname, steps, warmup, ctx, comm, generic=False, repeats=1, hos
         # PROF_STEPS fully bracketed steps before the timed region (a HIP-event bracket adds ~3 us of dispatch to a launch,
         # so the short kernels read low here; the rocprofv3 summary under profiles/ has the un-bracketed durations).
         # Each kernel is priced against the roofline that bounds it: HBM when its arithmetic intensity is below the ridge.
-        ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         roofline_all, step_bytes, step_flops = [], 0.0, 0.0
         for kname, klaunch, kms, kbytes, kflops in sorted(full_table, key=lambda r: -r[2]):
             if klaunch == 0:
@@ -191,18 +195,20 @@ def time_workload(wname, steps, warmup, ctx, comm, generic=False, repeats=1, hos
             us = 1e3 * kms / klaunch
             step_bytes += kbytes * klaunch / PROF_STEPS
             step_flops += kflops * klaunch / PROF_STEPS
+            kpeak = kernel_peak(kname)
+            ridge = kpeak * 1e12 / (HBM_PEAK_GBS * 1e9)
             hbm = kbytes <= 0 or kflops / max(kbytes, 1.0) < ridge
             ach = (kbytes / (us * 1e-6) / 1e9) if hbm else (kflops / (us * 1e-6) / 1e12)
             roofline_all.append({'kernel': kname, 'launches_per_step': round(klaunch / PROF_STEPS, 2), 'avg_us': round(us, 2),
                                  'algorithmic_bytes': kbytes, 'flops': kflops, 'bound': 'hbm' if hbm else 'mfma',
                                  'achieved': round(ach, 1), 'unit': 'GB/s' if hbm else 'TFLOP/s',
-                                 'frac': round(ach / (HBM_PEAK_GBS if hbm else mfma_peak), 4)})
+                                 'peak': HBM_PEAK_GBS if hbm else round(kpeak, 1),
+                                 'frac': round(ach / (HBM_PEAK_GBS if hbm else kpeak), 4)})
         step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
         frac = achieved / peak
         if wname != 'unet':                  # ONE figure per kernel: the dense legs quote the dominant kernel's `roofline_all` entry
             e = next(r for r in roofline_all if r['kernel'] == dominant)
-            bound, unit, achieved, frac = e['bound'], e['unit'], e['achieved'], e['frac']
-            peak = HBM_PEAK_GBS if bound == 'hbm' else mfma_peak
+            bound, unit, achieved, frac, peak = e['bound'], e['unit'], e['achieved'], e['frac'], e['peak']
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
         if os.path.exists(tpath) and wname == 'unet':
@@ -221,6 +227,8 @@ def time_workload(wname, steps, warmup, ctx, comm, generic=False, repeats=1, hos
                          'launches': int(launches), 'avg_launch_us': round(avg_ms * 1e3, 2),
                          'avg_launch_us_alone': round(avg_ms_alone * 1e3, 2), 'avg_launch_us_overlapped': round(avg_ms_region * 1e3, 2),
                          'frac_from': 'timed region brackets' if wname == 'unet' else 'serialised steps (avg_launch_us_alone)',
+                         'peak_note': ('fp32 results from six bf16 products per multiply-add on the bf16 matrix pipe (csrc/kernels_ig3x.hip): '
+                                       'peak = 2.5 PFLOP/s / 6 in fp32-equivalent FLOP/s' if dominant.startswith('ig3x_') else None),
                          'algorithmic_bytes_per_launch': bytes_per, 'flops_per_launch': flops_per,
                          'share_of_step': round(avg_ms * dominant_per_step / (ms_per_step if ms_per_step > 0 else 1e9), 4)},
             # the whole step against the HBM roofline: sum of the launches' algorithmic bytes (every tensor read
@@ -303,8 +311,12 @@ def main():
             owl = WORKLOADS[wname]
             others[wname] = {'metric': 'MRI slices/sec (fwd+bwd) %s 512x512 bs=%d' % (wname, owl['batch']), 'value': r['value'], 'unit': 'slices/s',
                              'ms_per_step': r['ms_per_step'], 'steps': n_other, 'dtype': r['dtype'], 'workload': r['workload'],
+                             'arithmetic': ('fp32 tensors and results; the dense 3x3 convs (forward, data and weight gradient) form each fp32 product from '
+                                            'six bf16 products of three-plane operands on the bf16 matrix pipe, fp32 accumulation (csrc/kernels_ig3x.hip; '
+                                            'DNNCA_NO_X3=1 runs them on the fp32 matrix pipe)') if owl['dtype'] == 'f32' else
+                                           'bf16 MFMA operands (RNE), fp32 master weights and accumulation, bf16-stored BatchNorm inputs / gradients',
                              'settle_steps': r['settle_steps'], 'region_ms': r['region_ms'],
-                             'roofline': {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_from', 'avg_launch_us',
+                             'roofline': {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'peak_note', 'unit', 'frac', 'frac_from', 'avg_launch_us',
                                                                         'avg_launch_us_alone', 'avg_launch_us_overlapped', 'share_of_step')},
                              'roofline_step': r['roofline_step'],
                              'top_kernels': r['roofline_all'][:6]}

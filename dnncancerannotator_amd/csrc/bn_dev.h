@@ -64,7 +64,9 @@ __device__ __forceinline__ double bn_fold_column(const double* tab, int R, int s
 constexpr int kBnGroups = 32;          // (the ticket array behind the table has 64 slots)
 __device__ __forceinline__ bool bn_last_block(unsigned* ticket, unsigned nblocks, unsigned bid) {
     __shared__ unsigned bn_last;
+#ifndef DNNCA_AB_NO_BN_WAIT          // (A/B arm of tools: the round-3 code without the wait; never shipped)
     __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): this thread's bucket adds have been performed (acknowledged)
+#endif
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned G = nblocks < (unsigned)kBnGroups ? nblocks : (unsigned)kBnGroups, g = bid % G;

@@ -25,15 +25,23 @@ def short_name(k):
     m = re.match(r'dnnca::k_pgfwd<(\d+), (\d+), (\d+), \d+, (?:true|false)(, true|, false)?>', k)
     if m:
         return 'pgfwd_%s%sx%s_%s' % ('head_' if m.group(4) == ', true' else '', m.group(1), m.group(2), m.group(3))
+    m = re.match(r'dnnca::ig3x::k_ig3x_conv3<(\d+), (\d+), (\d+)(?:, (\d+))?>', k)
+    if m:      # channel tile 16 NN, mode (0 forward / 1 data gradient), waves, channel split
+        return 'ig3x_conv_%s#x3n%sw%s%s' % ('dgrad' if m.group(2) == '1' else 'fwd', m.group(1), m.group(3), 's' if m.group(4) == '2' else '')
+    m = re.match(r'dnnca::ig3x::k_ig3x_wgrad<(\d+), (\d+), (\d+), (\d+)>', k)
+    if m:
+        return 'ig3x_wgrad#x3m%sj%sn%sk%s' % m.groups()
     m = re.match(r'dnnca::k_(pool2_bwd|pool2_fwd|head_train|head_reduce)<(\d+)', k)
     if m:
         return '%s_%s' % m.groups()
     m = re.match(r'dnnca::k_(tconv2_fwd|tconv_bwd)<(\d+), (\d+)', k)
     if m:
         return '%s_%s_%s' % m.groups()
-    m = re.match(r'dnnca::fz::k_fz_(down|up)<(\d+), (\d+)((?:, \d+)*)>', k)
+    m = re.match(r'dnnca::fz::k_fz_(down|up)<(\d+), (\d+)((?:, \w+)*)>', k)
     if m:
-        extra = [t.strip() for t in m.group(4).split(',') if t.strip()]     # TW, TH, NT, MINW[, NF]
+        extra = [t.strip() for t in m.group(4).split(',') if t.strip()]     # TW, TH, NT, MINW[, NF[, NOTC]]
+        if len(extra) >= 6 and extra[5] == 'true':
+            return 'fz_up2_%s' % m.group(3)
         ride = 'tc_' if m.group(1) == 'up' and len(extra) >= 5 and extra[4] != '0' else ''
         return 'fz_%s_%s%s_%s' % (m.group(1), ride, m.group(2), m.group(3))
     m = re.match(r'dnnca::fzb::k_fzb<(true|false), (\d+), (\d+)', k)
