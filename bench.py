@@ -242,7 +242,7 @@ def time_workload(wname, steps, warmup, ctx, comm, generic=False, repeats=1, hos
         }
         if host_leg:
             # informative, never `value`: the same steps with every batch starting in (pageable) host memory -- uploads into the
-            # model's staging ring on the copy stream, step scalars read one step late (tools/e2e_rate.py)
+            # model's staging ring on the copy stream, step scalars read one step late (NOTES.md 4b; tools/e2e_rate.py)
             ring = model.staging()
             hb = [synthetic_batch(B, H, W, C, seed_x=300 + i, seed_y=400 + i) for i in range(2)]
             n_host, prev = max(20, steps // 2), None

@@ -65,7 +65,7 @@ struct ConvArgs {
 // 2.1 -> 3.2 ms of dgrad against 0.7 ms saved; with this epilogue and two waves per SIMD +0.44 ms of dgrad against 0.63 ms on
 // unet_big, and a net loss on mulmo_unet, where the fold of the per-tile partials also grows.  Round 3, with the self-folding
 // bucket rows of bn_dev.h and the sums taken from the stored bf16 values: 98 -> 192 us per launch -- the 16 two-byte loads per tile
-// row cannot move above the previous row's stores, four exposed round trips per unit.  DESIGN.md section 6.)
+// row cannot move above the previous row's stores, four exposed round trips per unit.  NOTES.md, section 6 of the round-3 document.)
 template <int NN, int MODE, int NW = 4>
 __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0, int tile,
                                                float* red) {
