@@ -2170,7 +2170,9 @@ __global__ __launch_bounds__(256, 1) void k_igb_tconv_wgrad64(TcArgs p) {
 // ================================================================================================ host side
 struct IgPlan {
     bool built = false;
-    std::vector<ig::FlipDesc> flips;
+    std::vector<ig::FlipDesc> flips;          // eager ones first (n_eager), then the convs the split-bf16 kernels cover (flipped only on demand)
+    int n_eager = 0;
+    std::map<size_t, int> flip_index;         // w_off -> index in flips
     ig::FlipDesc* flips_dev = nullptr;
     float* flipped = nullptr;        // same layout / offsets as the parameter vector (only conv kernels are filled)
     int max_w = 0;
@@ -2326,17 +2328,34 @@ int ig_plan_half(Model* m) {
     return DNNCA_OK;
 }
 
+static bool conv3_path(const ig::ConvArgs& a, int cout, bool bf16);
+
 int ig_prepare(Model* m) {
     if (m->desc.flags & 1) return DNNCA_OK;
     IgPlan& pl = g_ig[m];
     if (!pl.built) {
         pl.built = true;
-        for (const Op& o : m->ops) {
-            if (!ig_conv_supported(m, o) || !o.need_din || use_bf16(m, o)) continue;
-            ig::FlipDesc d{(int)o.w_off, o.inA.d.C + o.inB.d.C, o.out.d.C};
-            pl.flips.push_back(d);
-            int n = 9 * d.cin * d.cout;
-            if (n > pl.max_w) pl.max_w = n;
+        // the data-gradient kernels of the fp32 MFMA path read flipped / transposed weights (k_ig_flip, once per backward pass); the
+        // split-bf16 kernels have their own planes (ig3x_prepare), so convs they will take (the same static conditions ig3x_launch checks,
+        // at max_batch) are only flipped on demand (launch_ig, should the split-bf16 launch ever decline)
+        for (int pass = 0; pass < 2; ++pass) {
+            for (const Op& o : m->ops) {
+                if (!ig_conv_supported(m, o) || !o.need_din || use_bf16(m, o)) continue;
+                const int cin = o.inA.d.C + o.inB.d.C, cout = o.out.d.C;
+                ig::ConvArgs gd{};
+                gd.c_src0 = cout; gd.n_dst0 = o.inA.d.C; gd.n_dst1 = o.inB.d.C;
+                gd.B = m->desc.max_batch; gd.H = o.out.d.H; gd.W = o.out.d.W;
+                const bool covered = ig3x_enabled(m) && conv3_path(gd, cin, false) && cin <= 1024 && 9.0 * cin * cout + 2.0 * (m->nT + 16) <= 1.0e9;
+                if (covered != (pass == 1)) continue;
+                ig::FlipDesc d{(int)o.w_off, cin, cout};
+                pl.flip_index[o.w_off] = (int)pl.flips.size();
+                pl.flips.push_back(d);
+                if (pass == 0) {
+                    ++pl.n_eager;
+                    int n = 9 * d.cin * d.cout;
+                    if (n > pl.max_w) pl.max_w = n;
+                }
+            }
         }
         for (const Op& o : m->ops) {
             if (!ig_conv_supported(m, o) || !use_bf16(m, o)) continue;
@@ -2380,11 +2399,11 @@ int ig_prepare(Model* m) {
 int ig_begin_backward(Model* m) {
     if (m->desc.flags & 1) return DNNCA_OK;
     IgPlan& pl = g_ig[m];
-    if (pl.flips.empty()) return DNNCA_OK;
+    if (pl.n_eager == 0) return DNNCA_OK;
     int bx = (pl.max_w + 255) / 256;
     if (bx > 1024) bx = 1024;
     LAUNCH(m, "ig_flip", 8.0 * m->nT, 0,
-           hipLaunchKernelGGL(ig::k_ig_flip, dim3(bx, (unsigned)pl.flips.size()), dim3(256), 0, m->stream, pl.flips_dev, m->p, pl.flipped));
+           hipLaunchKernelGGL(ig::k_ig_flip, dim3(bx, (unsigned)pl.n_eager), dim3(256), 0, m->stream, pl.flips_dev, m->p, pl.flipped));
     return DNNCA_OK;
 }
 
@@ -2428,6 +2447,17 @@ static void launch_ig(Model* m, const ig::ConvArgs& a, size_t w_off, int cout, c
             // fp32 by three bf16 planes on the bf16 matrix pipe (kernels_ig3x.hip), unless switched off
             if (ig3x_launch(m, MODE, a, w_off, cout, nnx, MODE == 0 ? "ig3x_conv_fwd" : "ig3x_conv_dgrad", bytes, flops))
                 return;
+            if (MODE == 1) {          // declined although the plan expected it: this conv's flipped weights were not made at ig_begin_backward
+                IgPlan& plz = g_ig[m];
+                auto it = plz.flip_index.find(w_off);
+                if (it != plz.flip_index.end() && it->second >= plz.n_eager) {
+                    const ig::FlipDesc& fd = plz.flips[it->second];
+                    int bx = (9 * fd.cin * fd.cout + 255) / 256;
+                    if (bx > 1024) bx = 1024;
+                    LAUNCH(m, "ig_flip", 8.0 * 9 * fd.cin * fd.cout, 0,
+                           hipLaunchKernelGGL(ig::k_ig_flip, dim3(bx, 1), dim3(256), 0, m->stream, plz.flips_dev + it->second, m->p, plz.flipped));
+                }
+            }
             ig::ConvArgs a2 = a;
             const int nw = ig_waves(a, cout);
             a2.tiles_x = (a.W + ig::F3T - 1) / ig::F3T;
