@@ -202,6 +202,15 @@ struct Model {
     std::vector<Rec> recs;
     std::vector<hipEvent_t> evpool;
 
+    // mulmo: the encoders (unet.py:152-165) are identical in shape and independent until the bottleneck concat; their ops sit one
+    // encoder after the other in `ops` (enc_ops each, n_enc of them, from index 0).  Both passes walk them in LOCKSTEP (op j of every
+    // encoder, then op j + 1, ...) so that one launch can serve the twin ops of all encoders (fast_bn_bwd_mp, ...): at op j of the
+    // first encoder visited, the inputs of every encoder's op j are ready.  enc_ops = 0: no such structure.
+    int enc_ops = 0, n_enc = 0;
+    bool lockstep() const;
+    std::vector<int> pass_order(bool backward) const;      // op indices in the order a pass visits them
+    std::vector<char> op_done;                              // per pass: this op's work rode in an earlier launch of the pass
+
     ~Model();
     int build();
     int alloc(void** ptr, size_t bytes);

@@ -390,6 +390,23 @@ int Model::build() {
             if (bb) o.src_bn[1] = b;
         }
     }
+    // twin structure of the mulmo encoders (model.h: lockstep)
+    enc_ops = n_enc = 0;
+    if (mulmo && nenc > 1) {
+        size_t first_dec = 0;
+        while (first_dec < ops.size() && ops[first_dec].name.compare(0, 7, "encoder") == 0) ++first_dec;
+        if (first_dec % nenc == 0 && first_dec > 0) {
+            const int per = (int)(first_dec / nenc);
+            bool same = true;
+            for (int e = 1; e < nenc && same; ++e)
+                for (int j = 0; j < per && same; ++j) {
+                    const Op &a = ops[j], &b = ops[(size_t)e * per + j];
+                    same = a.type == b.type && a.k == b.k && a.inA.d.C == b.inA.d.C && a.inA.d.H == b.inA.d.H && a.inA.d.W == b.inA.d.W &&
+                           a.inB.d.C == b.inB.d.C && a.out.d.C == b.out.d.C && a.out.d.H == b.out.d.H && a.out.d.W == b.out.d.W;
+                }
+            if (same) { enc_ops = per; n_enc = nenc; }
+        }
+    }
     fast_plan_masks(this);
     DN_TRY(ig_plan_half(this));
 
@@ -439,6 +456,39 @@ static bool all_f32(const Op& o) {
     return false;
 }
 
+bool Model::lockstep() const {
+    // OFF by default: nothing shares a launch across the encoders yet, and the order alone costs cache locality (pass_order).
+    // DNNCA_LOCKSTEP=1 walks the encoders in lockstep (the groundwork for one launch per twin-op triple; results are unchanged).
+    static const bool on = getenv("DNNCA_LOCKSTEP") != nullptr;
+    return on && enc_ops > 0 && !(desc.flags & 1);
+}
+
+std::vector<int> Model::pass_order(bool backward) const {
+    std::vector<int> ord;
+    const int n = (int)ops.size(), ne = lockstep() && !(backward && bucketing) ? enc_ops * n_enc : 0;
+    // Only the levels whose tensors are small walk in lockstep: at full resolution an op's output (134 MB at 8 x 512 x 512 x 16) is
+    // what the next op of the SAME encoder reads, largely out of the 256 MB Infinity Cache; with the other encoders' ops in between it
+    // comes from HBM.  Measured on mulmo_unet (8.93 ms sequential, same box): lockstep over all four levels 9.23 ms, levels <= 256^2
+    // 9.14, <= 128^2 9.00, <= 64^2 9.02 -- so only the two deep levels are candidates for shared launches.
+    static const int max_h = getenv("DNNCA_LOCKSTEP_MAXH") ? atoi(getenv("DNNCA_LOCKSTEP_MAXH")) : 128;
+    int j0 = 0;          // first op (relative index) of the lockstep part
+    while (ne && j0 < enc_ops && ops[j0].out.d.H > max_h) ++j0;
+    if (!backward) {
+        for (int e = 0; e < (ne ? n_enc : 0); ++e)
+            for (int j = 0; j < j0; ++j) ord.push_back(e * enc_ops + j);
+        for (int j = j0; j < (ne ? enc_ops : 0); ++j)
+            for (int e = 0; e < n_enc; ++e) ord.push_back(e * enc_ops + j);
+        for (int i = ne; i < n; ++i) ord.push_back(i);
+    } else {
+        for (int i = n - 1; i >= ne; --i) ord.push_back(i);
+        for (int j = (ne ? enc_ops : 0) - 1; j >= j0; --j)
+            for (int e = n_enc - 1; e >= 0; --e) ord.push_back(e * enc_ops + j);
+        for (int e = (ne ? n_enc : 0) - 1; e >= 0; --e)
+            for (int j = j0 - 1; j >= 0; --j) ord.push_back(e * enc_ops + j);
+    }
+    return ord;
+}
+
 int Model::forward(const float* x_dev, int B, bool training) {
     if (B < 1 || B > desc.max_batch) { set_error("batch %d outside [1, max_batch=%d]", B, desc.max_batch); return DNNCA_EINVAL; }
     last_batch = B;
@@ -474,8 +524,13 @@ int Model::forward(const float* x_dev, int B, bool training) {
     }
     head_in_conv.labels_done = head_in_conv_ok;
 
-    const Op* pool_done = nullptr;      // a max-pool that rode in the preceding conv's epilogue
-    for (size_t oi = 0; oi < ops.size(); ++oi) {
+    // op_done[i]: op i's work rode in an earlier launch of this pass (a max-pool in the preceding conv's / BatchNorm's launch, the
+    // later layers of a fused block, the twin ops of the other mulmo encoders)
+    const std::vector<int> order = pass_order(false);
+    op_done.assign(ops.size(), 0);
+    for (size_t ok_ = 0; ok_ < order.size(); ++ok_) {
+        size_t oi = (size_t)order[ok_];
+        if (op_done[oi]) continue;
         Op& o = ops[oi];
         cur_op = &o.name;
         switch (o.type) {
@@ -495,7 +550,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 }
                 if (oi == 0 && labels_in_first_block) {
                     if (!generic && fused_down_fwd(this, B, oi, training, labels_in_first_block)) {
-                        oi += 2;
+                        op_done[oi + 1] = op_done[oi + 2] = 1;
                         break;
                     }
                     // the first block did not take them: the label statistics get their own launch after all
@@ -504,16 +559,16 @@ int Model::forward(const float* x_dev, int B, bool training) {
                     labels_in_first_block = nullptr;
                 }
                 if (!generic && fused_down_fwd(this, B, oi, training)) {      // conv, conv, pool of one encoder block in one launch
-                    oi += 2;
+                    op_done[oi + 1] = op_done[oi + 2] = 1;
                     break;
                 }
                 if (!generic && o.inB.d.C && fused_up2_fwd(this, B, oi, training)) {      // the two convs of a decoder block (its transposed conv rode earlier)
-                    oi += 1;
+                    op_done[oi + 1] = 1;
                     break;
                 }
                 Op* pool = (!generic && oi + 1 < ops.size() && fast_pool_fusable(this, o, ops[oi + 1])) ? &ops[oi + 1] : nullptr;
                 if (!generic && fast_conv_fwd(this, B, o, bytes + (pool ? 4.0 * nelem(B, pool->out.d) : 0.0), flops, pool)) {
-                    pool_done = pool;
+                    if (pool) op_done[pool - ops.data()] = 1;
                     break;
                 }
                 Op* bn_next = (training && oi + 1 < ops.size() && ops[oi + 1].type == OP_BN && ops[oi + 1].inA.d.p == o.out.d.p &&
@@ -539,7 +594,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 Op* pool_bn = (bn_pool && training && oi + 2 < ops.size() && ops[oi + 2].type == OP_BN &&
                                ops[oi + 2].inA.d.p == bn_pool->out.d.p && fast_bn_supported(this, ops[oi + 2])) ? &ops[oi + 2] : nullptr;
                 if (!generic && fast_bn_fwd(this, B, o, training, kBnMomentum, kBnEps, bn_pool, pool_bn)) {
-                    if (bn_pool) pool_done = bn_pool;
+                    if (bn_pool) op_done[bn_pool - ops.data()] = 1;
                     break;
                 }
                 if (!all_f32(o)) return DNNCA_ESTATE;
@@ -555,7 +610,7 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 break;
             }
             case OP_POOL: {
-                if (pool_done == &o) break;          // computed by the conv that produced its input
+                // (a pool computed by the launch that produced its input never gets here: op_done)
                 double bytes = 4.0 * (nelem(B, o.inA.d) + nelem(B, o.out.d));
                 if (!generic && fast_pool_fwd(this, B, o, bytes)) break;
                 if (!all_f32(o)) return DNNCA_ESTATE;
@@ -567,11 +622,11 @@ int Model::forward(const float* x_dev, int B, bool training) {
                 double flops = 2.0 * nelem(B, o.out.d) * o.inA.d.C;
                 int used = 3;
                 if (!generic && fused_up_fwd(this, B, oi, training, &used)) { // tconv, conv, conv of one decoder block in one launch
-                    oi += used - 1;                                           // (+ the next block's tconv when it rides along)
+                    for (int t = 1; t < used; ++t) op_done[oi + t] = 1;       // (+ the next block's tconv when it rides along)
                     break;
                 }
                 if (!generic && fast_up3_fwd(this, B, oi)) {                  // tconv + two-source conv of the 3-channel level
-                    oi += 1;
+                    op_done[oi + 1] = 1;
                     break;
                 }
                 Op* bn_next = (training && oi + 1 < ops.size() && ops[oi + 1].type == OP_BN && ops[oi + 1].inA.d.p == o.out.d.p &&
@@ -671,7 +726,11 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
             bucketing = bucket_state == 1;
             bucket_hi = bucket_fin = nT;
         }
-        for (int i = (int)ops.size() - 1; i >= 0; --i) {
+        const std::vector<int> order = pass_order(true);          // (lockstep over the mulmo encoders unless this pass sends gradient buckets)
+        op_done.assign(ops.size(), 0);
+        for (size_t ok_ = 0; ok_ < order.size(); ++ok_) {
+            const int i = order[ok_];
+            if (op_done[i]) continue;
             Op& o = ops[i];
             cur_op = &o.name;
             if (bucketing && i + 1 < (int)ops.size()) {
@@ -707,7 +766,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                         break;
                     }
                     if (!generic && i >= 2 && fused_up_bwd(this, B, (size_t)i)) {       // second conv, first conv, transposed conv of a decoder block in one launch
-                        i -= 2;
+                        op_done[i - 1] = op_done[i - 2] = 1;
                         break;
                     }
                     if (!generic && (fast_conv_bwd(this, B, o, ob, ib, flops) || fast_first_conv_bwd(this, B, o, ob, ib, flops) ||
@@ -740,7 +799,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 case OP_POOL: {
                     double bytes = 4.0 * (2 * nelem(B, o.inA.d) + 2 * nelem(B, o.out.d));
                     if (!generic && i >= 2 && fused_down_bwd(this, B, (size_t)i)) {     // pool, second conv, first conv of an encoder block in one launch
-                        i -= 2;
+                        op_done[i - 1] = op_done[i - 2] = 1;
                         break;
                     }
                     if (!generic && i > 0 && fast_pool_into_bn(this, o, ops[i - 1])) break;   // rides in the backward passes of the BatchNorm in front of it
