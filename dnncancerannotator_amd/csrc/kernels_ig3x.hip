@@ -217,7 +217,11 @@ __device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)
 // WN = 2 (NW = 8 only): 16 x 16-pixel tiles like NW = 4, the eight waves are 4 row groups x 2 channel halves (8 NN channels... 16 NN / 2 each):
 // two waves per SIMD on layers that have too few 32 x 16 tiles to fill the chip (the 64^2 / 128^2 levels) -- a single wave per SIMD cannot
 // issue v_mfma_f32_16x16x32_bf16 back to back, and its LDS waits and barriers are nobody's cover.
-template <int NN, int MODE, int NW, int WN = 1>
+// DB: TWO LDS buffers (where they fit: 16-channel tiles on 32 x 16 pixels, 32-channel tiles on 16 x 16) -- the registers holding item
+// i + 1 are split and written into the other buffer, and item i + 2's loads issued, in slices woven between the 27 MFMA steps of item
+// i: one barrier per item, and the split's vector instructions run in the shadow of the MFMAs (the scheme of igb::k_igb_conv3).  These
+// are the full-resolution layers, bound by HBM and by the commit, not by the matrix pipe.
+template <int NN, int MODE, int NW, int WN = 1, bool DB = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_conv3(ConvArgs p, const bf16_t* __restrict__ w3, unsigned pstride) {
     static_assert(WN == 1 || (WN == 2 && NW == 8 && NN % 2 == 0), "channel split: eight waves, two halves");
     constexpr int NWR = NW / WN, NJ = NN / WN;            // row groups of waves; 16-channel tiles per wave
@@ -226,7 +230,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
     constexpr int APL = PATCHX * KC;                 // bf16 elements per A plane: [patch pixel][16 channels], 32-byte rows
     constexpr int BPL = 9 * COT * KC;                // per B plane: [tap][channel of the tile][16 K channels]
     constexpr int BOFF = 3 * APL, DUMP = BOFF + 3 * BPL, BUF = DUMP + 64;      // + a dump row for the idle lanes of the last staging element
-    __shared__ __attribute__((aligned(16))) bf16_t lds[BUF];
+    static_assert(!DB || 2 * BUF * 2 + 8192 <= 160 * 1024, "two buffers must fit");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[DB ? 2 * BUF : BUF];
     __shared__ float bn_red[NW * 2 * 16 * NJ];       // cross-wave fold of the fused BatchNorm statistics (epilogue_t)
     // the bias vector, read by the epilogue through LDS: a global load there queues behind the next item's prefetch (vmcnt retires in
     // order) and cost the epilogue of a 16-channel unit 4 k cycles of waiting (tools/x3_stamps.py)
@@ -342,6 +347,52 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
             }
         }
     };
+    // ---- the same per element, for the double-buffered loop: `cur` belongs to the item in the registers, `nxt` to the one being issued
+    float4 n_sc_nxt = n_sc, n_sh_nxt = n_sh;
+    unsigned a_in_nxt = 0u;
+    auto issue_a1 = [&](const Stage& st, int v) {
+        const int iy = st.y0 - 1 + a_ly[v], ix = st.x0 - 1 + a_lx[v];
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned off = (ok ? (unsigned)(((((st.b * p.H + iy) * p.W + ix) * st.cs) + st.c0 + 4 * c4) * 4) : OOB) | st.oob;
+        ar[v] = __builtin_amdgcn_raw_buffer_load_b128(st.rs, off, 0, 0);
+        a_in_nxt |= ok ? (1u << v) : 0u;
+    };
+    auto issue_b1 = [&](const Stage& st, int v) {
+        br[v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (b_off[v] == OOB ? OOB : (b_off[v] + st.wbase) * 2u) | st.oob, 0, 0);
+    };
+    auto stage_coef = [&](const Stage& st, float4& sc, float4& sh) {
+        sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* nt = p.norm[st.cc >= p.c_src0 ? 1 : 0];          // uniform
+        if (nt) {
+            sc = *reinterpret_cast<const float4*>(nt + st.c0 + 4 * c4);
+            sh = *reinterpret_cast<const float4*>(nt + st.cs + st.c0 + 4 * c4);
+        }
+    };
+    auto commit_a1 = [&](bf16_t* buf, int v) {
+        const int px = (tid >> 2) + (NT / 4) * v;
+        f32x4 f = __builtin_bit_cast(f32x4, ar[v]);
+        if (norm_any) {
+            const bool in = (a_in >> v) & 1u;
+            f[0] = in ? fmaf(f[0], n_sc.x, n_sh.x) : 0.f; f[1] = in ? fmaf(f[1], n_sc.y, n_sh.y) : 0.f;
+            f[2] = in ? fmaf(f[2], n_sc.z, n_sh.z) : 0.f; f[3] = in ? fmaf(f[3], n_sc.w, n_sh.w) : 0.f;
+        }
+        bf16x4 h0, h1, h2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16_t x0, x1, x2;
+            split3(f[e], x0, x1, x2);
+            h0[e] = x0; h1[e] = x1; h2[e] = x2;
+        }
+        bf16_t* dst = buf + (px < PATCHX ? px * KC : DUMP) + 4 * c4;          // idle lanes (last element only): the dump row
+        *reinterpret_cast<bf16x4*>(dst) = h0;
+        *reinterpret_cast<bf16x4*>(dst + (px < PATCHX ? APL : 16)) = h1;
+        *reinterpret_cast<bf16x4*>(dst + (px < PATCHX ? 2 * APL : 32)) = h2;
+    };
+    auto commit_b1 = [&](bf16_t* buf, int v) {
+        const int i = tid + NT * v;
+        *reinterpret_cast<u32x4*>(buf + (i < NPIECE ? BOFF + 8 * i : DUMP + 8 * (i & 7))) = br[v];
+    };
     auto commit_item = [&]() {
 #pragma unroll
         for (int v = 0; v < AU; ++v) {
@@ -380,6 +431,96 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
     const bf16_t* bP[3] = {b_base, b_base + BPL, b_base + (hA ? 0 : 2 * BPL)};          // (b0 | b0), (b1 | b1), (b2 | b0)
 
     f32x4 acc[4][NJ];
+    if constexpr (DB) {
+        static_assert(AU + BU <= 12, "staging slices of the 27 MFMA steps");
+        // prologue: item 0 into buffer 0, item 1 into the registers
+        {
+            const Stage s0 = next_stage();
+            if (norm_any) stage_coef(s0, n_sc, n_sh);
+#pragma unroll
+            for (int v = 0; v < AU; ++v) issue_a1(s0, v);
+#pragma unroll
+            for (int v = 0; v < BU; ++v) issue_b1(s0, v);
+            a_in = a_in_nxt;
+            a_in_nxt = 0u;
+#pragma unroll
+            for (int v = 0; v < AU; ++v) commit_a1(lds, v);
+#pragma unroll
+            for (int v = 0; v < BU; ++v) commit_b1(lds, v);
+            const Stage s1 = next_stage();
+            if (norm_any) stage_coef(s1, n_sc, n_sh);
+#pragma unroll
+            for (int v = 0; v < AU; ++v) issue_a1(s1, v);
+#pragma unroll
+            for (int v = 0; v < BU; ++v) issue_b1(s1, v);
+            a_in = a_in_nxt;
+            a_in_nxt = 0u;
+        }
+        lds_barrier();
+        int it = 0;
+#pragma unroll 1
+        for (int k = 0; k < my_units; ++k) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
+                const int boff = (it & 1) * BUF;
+                bf16_t* other = lds + ((it & 1) ^ 1) * BUF;
+                const Stage nx = next_stage();                        // item it + 2
+                if (norm_any) stage_coef(nx, n_sc_nxt, n_sh_nxt);     // used by the NEXT item's commits
+                bf16x8 fa[2][6], fb[2][NJ];
+                auto load_a = [&](bf16x8 (&a)[6], const bf16_t* base, int g) {
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) a[rr] = *reinterpret_cast<const bf16x8*>(base + boff + (rr * (T + 2) + g) * KC);
+                };
+                auto load_b = [&](bf16x8 (&b)[NJ], int pr, int tap) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bP[pr] + boff + (tap * COT + 16 * j) * KC);
+                };
+                auto mfmas = [&](const bf16x8 (&a)[6], const bf16x8 (&b)[NJ], int dy) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[r + dy], acc[r][j], 0, 0, 0);
+                };
+                load_a(fa[0], aX, 0);
+                load_b(fb[0], 0, 0);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                    for (int s = 0; s < 9; ++s) {
+                        const int dy = s < 6 ? s >> 1 : s - 6, cur = (9 * g + s) & 1, step = 9 * g + s;
+                        if (s == 0) load_a(fa[1], aY, g);
+                        if (s == 6 && g < 2) load_a(fa[0], aX, g + 1);
+                        if (s < 8 || g < 2) {
+                            const int s1 = s < 8 ? s + 1 : 0, g1 = s < 8 ? g : g + 1;
+                            const int dy1 = s1 < 6 ? s1 >> 1 : s1 - 6, pr1 = s1 < 6 ? (s1 & 1) : 2;
+                            load_b(fb[cur ^ 1], pr1, dy1 * 3 + g1);
+                        }
+                        // staging slice: every second step commits one element of item it + 1 into the other buffer and re-uses its
+                        // registers for item it + 2 (unconditional: past the last item the loads are out of range and the commit
+                        // writes a buffer nobody reads again)
+                        if (step >= 1 && (step & 1) && (step >> 1) < AU + BU) {
+                            const int v = step >> 1;
+                            if (v < AU) { commit_a1(other, v); issue_a1(nx, v); }
+                            else { commit_b1(other, v - AU); issue_b1(nx, v - AU); }
+                        }
+                        mfmas(fa[s < 6 ? 0 : 1], fb[cur], dy);
+                    }
+                }
+                n_sc = n_sc_nxt; n_sh = n_sh_nxt;          // the registers now hold item it + 2
+                a_in = a_in_nxt;
+                a_in_nxt = 0u;
+                lds_barrier();
+            }
+            const Unit u = unit_of(k);
+            epilogue_t<NJ, MODE, NWR, WN>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red, bias_lds);
+        }
+        if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);
+        return;
+    }
     issue_item(next_stage());
     int it = 0;
 #pragma unroll 1
@@ -752,6 +893,7 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
     if (9.0 * cout * (a.c_src0 + a.c_src1) + 2.0 * pl.pstride > 1.0e9) return false;          // 32-bit byte offsets into the planes
     static const int forced = getenv("DNNCA_IG_NW") ? atoi(getenv("DNNCA_IG_NW")) : 0;
     static const bool no_split = getenv("DNNCA_X3_NO_SPLIT") != nullptr;          // tuning aid
+    static const bool no_db = getenv("DNNCA_X3_NO_DB") != nullptr;                // tuning aid / A-B arm
     const long units8 = (long)((a.W + 15) / 16) * ((a.H + 31) / 32) * a.B * (cout / (16 * nn));
     int nw = 8, wn = 1;
     if (forced == 4) nw = 4;
@@ -759,6 +901,9 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
         if (nn >= 2 && !no_split) wn = 2;
         else nw = 4;
     }
+    // two LDS buffers where they fit: 16-channel tiles on 32 x 16 pixels, 32-channel tiles on the split 16 x 16 layout
+    if (nn == 2 && nw == 8 && !no_db && !no_split && forced != 8) wn = 2;
+    const bool db = !no_db && nw == 8 && ((nn == 1 && wn == 1) || (nn == 2 && wn == 2));
     const int rows = 4 * (nw / wn);
     ig::ConvArgs a2 = a;
     a2.tiles_x = (a.W + ig3x::T - 1) / ig3x::T;
@@ -774,11 +919,13 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
          {ig3x::k_ig3x_conv3<2, 1, 4>, ig3x::k_ig3x_conv3<2, 1, 8>, ig3x::k_ig3x_conv3<2, 1, 8, 2>},
          {ig3x::k_ig3x_conv3<4, 1, 4>, ig3x::k_ig3x_conv3<4, 1, 8>, ig3x::k_ig3x_conv3<4, 1, 8, 2>}}};
     const int ni = nn == 4 ? 2 : (nn == 2 ? 1 : 0), li = wn == 2 ? 2 : (nw == 8 ? 1 : 0);
-    const Kern kern = kerns[mode ? 1 : 0][ni][li];
+    static const Kern kerns_db[2][2] = {{ig3x::k_ig3x_conv3<1, 0, 8, 1, true>, ig3x::k_ig3x_conv3<2, 0, 8, 2, true>},
+                                        {ig3x::k_ig3x_conv3<1, 1, 8, 1, true>, ig3x::k_ig3x_conv3<2, 1, 8, 2, true>}};
+    const Kern kern = db ? kerns_db[mode ? 1 : 0][ni] : kerns[mode ? 1 : 0][ni][li];
     // a persistent kernel's grid is the number of blocks that are resident at once: several per CU where LDS and registers allow
     // (a block alternates between committing an item and running its MFMAs; co-resident blocks fill each other's commit phases)
-    static int occ[2][3][3] = {};
-    int& oc = occ[mode ? 1 : 0][ni][li];
+    static int occ[2][3][4] = {};
+    int& oc = occ[mode ? 1 : 0][ni][db ? 3 : li];
     if (oc == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64 * nw, 0) != hipSuccess || nb < 1) nb = 1;
@@ -789,7 +936,7 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
     const unsigned resident = 256u * (unsigned)oc;
     const unsigned g = units < resident ? units : resident;
     const ig3x::bf16_t* w3 = (mode == 0 ? pl.wf : pl.wd) + w_off;
-    m->set_variant("x3n%dw%d%s", nn, nw, wn == 2 ? "s" : "");
+    m->set_variant("x3n%dw%d%s%s", nn, nw, wn == 2 ? "s" : "", db ? "d" : "");
     LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL(kern, dim3(g), dim3(64 * nw), 0, m->stream, a2, w3, pl.pstride));
     return true;
 }

@@ -429,7 +429,8 @@ def test_fp32_eight_wave_conv_kernels_against_oracle(gpu, alpha, x3):
     bad = {n: e for n, e in o['errs'].items() if not e <= (2e-5 if not alpha else 1e-4) + o['floors'][n]}
     assert not bad, bad
     if x3:
-        want = {'ig3x_conv_fwd#x3n1w8', 'ig3x_conv_fwd#x3n2w8', 'ig3x_conv_fwd#x3n4w8', 'ig3x_conv_dgrad#x3n1w8', 'ig3x_conv_dgrad#x3n2w8', 'ig3x_conv_dgrad#x3n4w8'}
+        # (16-channel tiles on eight waves run the double-buffered variant: x3n1w8d)
+        want = {'ig3x_conv_fwd#x3n1w8d', 'ig3x_conv_fwd#x3n2w8', 'ig3x_conv_fwd#x3n4w8', 'ig3x_conv_dgrad#x3n1w8d', 'ig3x_conv_dgrad#x3n2w8', 'ig3x_conv_dgrad#x3n4w8'}
     else:
         want = {'ig_conv_fwd#3n1w8', 'ig_conv_fwd#3n2w8', 'ig_conv_dgrad#3n1w8', 'ig_conv_dgrad#3n2w8'}
     assert want <= set(o['plan']), o['plan']
