@@ -69,6 +69,7 @@ const DenseSwitches& dense_switches();
 // implicit-GEMM MFMA path for channel counts that are multiples of 16 (kernels_igemm.hip)
 bool ig_conv_supported(const Model* m, const Op& o);
 int ig_prepare(Model* m);
+int ig_finish_wgrad(Model* m);      // the backward pass's weight-gradient slab folds in one launch (before the streams join)
 int ig_plan_half(Model* m);        // dtype bf16: decides View::h for every tensor (static per model; after fast_plan_masks)
 int ig_begin_backward(Model* m);
 void ig_release(Model* m);

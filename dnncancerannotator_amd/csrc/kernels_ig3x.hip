@@ -747,6 +747,9 @@ __global__ __launch_bounds__(512, 2) void k_ig3x_wgrad(ig::WgArgs p) {
         issue(tile + p.psplit);     // in flight during this tile's MFMAs (past the end: nothing)
 #pragma unroll 1
         for (int s = 0; s < NKS; ++s) {
+            // (unrolling this loop over consecutive row pairs of one column half shares patch rows between steps -- 0.56 instead of 0.89
+            // transposing reads per MFMA, the launch alone 60.3 -> 55.7 us -- and made the mulmo_unet STEP 1.5 % slower, beside the data-
+            // gradient launches of the main stream: round-4 log in NOTES.md.  Not kept.)
             const int ks = wk + WK * s, rp = ks >> 1, ch = (ks & 1) * 8;          // tile rows 2 rp, 2 rp + 1; columns ch .. ch + 7
             bf16x8 gv[3][NJ];
 #pragma unroll

@@ -8,6 +8,7 @@
 // 288 (NN = 4) MFMAs per wave between two barriers; the decoder concat is two sources, never materialised; bias +
 // activation (forward) or act' mask + accumulate + destination split (data gradient) are fused into the store.
 // The data gradient is the forward kernel on a transposed + flipped copy of the weights (k_ig_flip, once per step).
+#include <cstring>
 #include <type_traits>
 
 #include "bn_dev.h"
@@ -444,50 +445,80 @@ __global__ __launch_bounds__(256) void k_wg_fold(float* __restrict__ slabs, int 
     else dbias[i - n_w] += s;
 }
 
-// WgArgs::plain: the sum of a launch's psplit slabs goes into the gradient.  A slab is [9][cs][cout] (+ cout bias sums when n_b > 0); the
-// gradient rows of this source sit at input channels ci_off .. ci_off + cs of [9][cin_total][cout].  One thread = four consecutive floats
-// of a slab; the slabs are not re-zeroed (every launch stores every element of every slab).
-template <int G>      // slab groups per block: 256 / G quads x G groups (small gradients: few quads, many slabs -> G = 16; large: G = 1)
-__global__ __launch_bounds__(256) void k_wg_fold_plain(const float* __restrict__ slabs, int nb, int stride, int cs, int cout, int cin_total,
-                                                       int ci_off, float* __restrict__ dw, float* __restrict__ dbias, int n_b) {
+// One fold (a launch's slabs -> the gradient rows of its source) as the batched kernel sees it.
+struct FoldSeg {
+    const float* slabs;
+    float* dw;               // the conv's gradient [9][cin_total][cout]
+    float* dbias;
+    int nb, stride, cs, cout, cin_total, ci_off, n_b;
+    int g16;                 // 1: the 16-group block shape (small gradients), 0: one group
+};
+
+// slab groups per block: 256 / G quads x G groups (small gradients: few quads, many slabs -> G = 16; large: G = 1)
+template <int G>
+__device__ __forceinline__ void wg_fold_plain_block(const FoldSeg& f, int block, f32x4* red) {
     // thread (quad qi, group g) sums slabs g, g + G, ... (eight loads in flight); the groups meet in LDS
     constexpr int Q = 256 / G;
-    __shared__ f32x4 red[G][Q + 1];
-    const int n_w = 9 * cs * cout;
+    const int n_w = 9 * f.cs * f.cout;
     const int qi = threadIdx.x % Q, g = threadIdx.x / Q;
-    const int i = 4 * (blockIdx.x * Q + qi);
-    const bool live = i < n_w + n_b;
+    const int i = 4 * (block * Q + qi);
+    const bool live = i < n_w + f.n_b;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     if (live) {
         constexpr int U = 8;
-        for (int b0 = g; b0 < nb; b0 += G * U) {
+        for (int b0 = g; b0 < f.nb; b0 += G * U) {
             f32x4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int b = b0 + G * u;
-                v[u] = *reinterpret_cast<const f32x4*>(slabs + (size_t)(b < nb ? b : g) * stride + i);
+                v[u] = *reinterpret_cast<const f32x4*>(f.slabs + (size_t)(b < f.nb ? b : g) * f.stride + i);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (b0 + G * u < nb) s += v[u];
+                if (b0 + G * u < f.nb) s += v[u];
         }
     }
     if (G > 1) {
-        red[g][qi] = s;
+        red[g * (Q + 1) + qi] = s;
         __syncthreads();
         if (g != 0) return;
 #pragma unroll
-        for (int k = 1; k < G; ++k) s += red[k][qi];
+        for (int k = 1; k < G; ++k) s += red[k * (Q + 1) + qi];
     }
     if (!live) return;
     if (i < n_w) {
-        const int t = i / (cs * cout), r = i - t * (cs * cout);          // cout % 4 == 0: the quad stays inside one row
-        float* d = dw + ((size_t)t * cin_total + ci_off) * cout + r;
+        const int t = i / (f.cs * f.cout), r = i - t * (f.cs * f.cout);          // cout % 4 == 0: the quad stays inside one row
+        float* d = f.dw + ((size_t)t * f.cin_total + f.ci_off) * f.cout + r;
         *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
     } else {
-        float* d = dbias + (i - n_w);
+        float* d = f.dbias + (i - n_w);
         *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
     }
+}
+constexpr int kFoldRed = 16 * 17;      // f32x4 entries of the G = 16 shape
+
+// WgArgs::plain: the sum of a launch's psplit slabs goes into the gradient.  A slab is [9][cs][cout] (+ cout bias sums when n_b > 0); the
+// gradient rows of this source sit at input channels ci_off .. ci_off + cs of [9][cin_total][cout].  One thread = four consecutive floats
+// of a slab; the slabs are not re-zeroed (every launch stores every element of every slab).
+template <int G>
+__global__ __launch_bounds__(256) void k_wg_fold_plain(FoldSeg f) {
+    __shared__ f32x4 red[G > 1 ? kFoldRed : 1];
+    wg_fold_plain_block<G>(f, blockIdx.x, red);
+}
+
+// Every fold of a backward pass in ONE launch (single-replica steps: nothing reads the gradient before the optimizer): `first[s]` is
+// the first block of segment s (first[nseg] = the grid), nseg <= 64 -- lane s of each wave compares its entry, the ballot counts the
+// segments that start at or before this block.
+constexpr int kFoldBatch = 64;
+__global__ __launch_bounds__(256) void k_wg_fold_batch(const FoldSeg* __restrict__ segs, const int* __restrict__ first, int nseg) {
+    __shared__ f32x4 red[kFoldRed];
+    const int lane = threadIdx.x & 63;
+    const int mine = lane < nseg ? first[lane] : 0x7fffffff;
+    const int s = __builtin_amdgcn_readfirstlane(__popcll(__ballot(mine <= (int)blockIdx.x)) - 1);
+    const int b0 = __builtin_amdgcn_readfirstlane(first[s]);
+    const FoldSeg f = segs[s];
+    if (f.g16) wg_fold_plain_block<16>(f, blockIdx.x - b0, red);
+    else wg_fold_plain_block<1>(f, blockIdx.x - b0, red);
 }
 
 // forward / data gradient, fp32, persistent and software-pipelined: the f32 twin of igb::k_igb_conv3 (see there for the
@@ -1816,7 +1847,9 @@ __global__ __launch_bounds__(512, 1) void k_igb_wgrad64w(ig::WgArgs p) {
         }
         const bf16_t* ximg = ximg2[buf];
         const bf16_t* gimg = gimg2[buf];
-#pragma unroll 1
+        // the four steps of a tile unrolled: consecutive steps share two of their four patch rows per dx, and the compiler merges the
+        // repeated transposing reads -- 46 reads per 72 MFMAs instead of 64 (the LDS pipe was the busier one): 79.3 -> 74.5 us per launch
+#pragma unroll
         for (int s = 0; s < TY / 2; ++s) {
             bf16x8 bv[NJ];
 #pragma unroll
@@ -2184,6 +2217,17 @@ struct IgPlan {
     int max_wb = 0;
     float* wg_slabs = nullptr;       // WG_BUCKETS copies of a small layer's weight + bias gradient (ig_wgrad2; left zeroed by k_wg_fold)
     std::map<std::pair<const void*, int>, std::pair<float*, size_t>> plain;      // (op, source) -> slabs of its plain-mode weight gradient, floats
+    // the folds of this backward pass, launched together by ig_finish_wgrad (single-replica steps); the device copies of the tables are
+    // rewritten only when the list changes (first step, another batch size)
+    std::vector<ig::FoldSeg> fold_pending, fold_on_dev;
+    ig::FoldSeg* fold_dev = nullptr;
+    int* fold_first_dev = nullptr;
+    size_t fold_cap = 0;
+    double fold_bytes = 0;
+    // DNNCA_FOLD_BATCH=1, read per step by ig_prepare (the tests flip it).  Opt-in: measured 0.2 - 0.4 % SLOWER on both dense
+    // configurations -- the one fold is shorter than the many (159 against 252 / 347 us) but sits at the end of the backward pass,
+    // where nothing overlaps it
+    bool fold_batch = false;
 };
 constexpr int WG_BUCKETS = 16, WG_SLAB_FLOATS = 131072 + 1024;
 static std::map<Model*, IgPlan> g_ig;
@@ -2208,6 +2252,9 @@ static bool wg_plain_on() {
     static const bool off = getenv("DNNCA_NO_WG_PLAIN") != nullptr;          // keep the float atomics (A/B)
     return !off;
 }
+// DNNCA_FOLD_BATCH=1: one fold launch per backward pass instead of one per weight-gradient launch -- unless this step sends gradient
+// buckets while the backward pass runs (they need each layer's gradient final as soon as its launches are)
+static bool wg_fold_batched(Model* m) { return g_ig[m].fold_batch && !m->bucketing; }
 
 const DenseSwitches& dense_switches() {
     static const DenseSwitches sw = {getenv("DNNCA_IGCONV1") != nullptr, getenv("DNNCA_WGRAD1") != nullptr, getenv("DNNCA_NO_BN_FUSION") != nullptr,
@@ -2385,6 +2432,9 @@ int ig_prepare(Model* m) {
         }
     }
     DN_TRY(ig3x_prepare(m));
+    pl.fold_pending.clear();          // (a step that failed half-way may have left some)
+    pl.fold_bytes = 0;
+    pl.fold_batch = getenv("DNNCA_FOLD_BATCH") != nullptr;
     if (!pl.preps.empty()) {
         int bx = (pl.max_wb + 255) / 256;
         if (bx > 1024) bx = 1024;
@@ -2627,25 +2677,29 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
                 if (!wg_plain_on() || bucketed) return false;
                 float* slabs = m->dry ? nullptr : wg_plain_slabs(m, o, s, (size_t)ps * pstride);
                 if (!m->dry && !slabs) return false;
+                w.nbuckets = 1;
+                w.plain = 1;
                 w.dw = slabs;
                 w.dbias = s == 0 ? slabs + n_ws : nullptr;
                 w.cin_total = w.cs;
                 w.ci_off = 0;
-                w.nbuckets = 1;
                 w.bucket_stride = pstride;
-                w.plain = 1;
                 return true;
             };
             auto fold_plain = [&](int ps) {
                 const int n_b = s == 0 ? CO : 0;
-                if (n_ws + n_b >= 32768)
+                const ig::FoldSeg f{w.dw, m->g + o.w_off, m->g + o.b_off, ps, pstride, w.cs, CO, CA + CB, s == 0 ? 0 : CA, n_b, n_ws + n_b < 32768};
+                if (wg_fold_batched(m)) {
+                    pl.fold_pending.push_back(f);
+                    pl.fold_bytes += 4.0 * ps * (n_ws + n_b);
+                    return;
+                }
+                if (!f.g16)
                     LAUNCH(m, "wg_fold", 4.0 * ps * (n_ws + n_b), 0,
-                           hipLaunchKernelGGL(ig::k_wg_fold_plain<1>, dim3((n_ws + n_b + 1023) / 1024), dim3(256), 0, m->stream, w.dw, ps, pstride, w.cs,
-                                              CO, CA + CB, s == 0 ? 0 : CA, m->g + o.w_off, m->g + o.b_off, n_b));
+                           hipLaunchKernelGGL(ig::k_wg_fold_plain<1>, dim3((n_ws + n_b + 1023) / 1024), dim3(256), 0, m->stream, f));
                 else
                     LAUNCH(m, "wg_fold", 4.0 * ps * (n_ws + n_b), 0,
-                           hipLaunchKernelGGL(ig::k_wg_fold_plain<16>, dim3((n_ws + n_b + 63) / 64), dim3(256), 0, m->stream, w.dw, ps, pstride, w.cs,
-                                              CO, CA + CB, s == 0 ? 0 : CA, m->g + o.w_off, m->g + o.b_off, n_b));
+                           hipLaunchKernelGGL(ig::k_wg_fold_plain<16>, dim3((n_ws + n_b + 63) / 64), dim3(256), 0, m->stream, f));
             };
             if (use_bf16(m, o) && CO % 64 == 0 && w.cs % 64 == 0) {
                 const int combos64 = (w.cs / 64) * (CO / 64);
@@ -2736,6 +2790,49 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
     if (!wg_last) { weight_gradient(); data_gradient(); }
     else { data_gradient(); weight_gradient(); }
     return true;
+}
+
+// end of the backward pass: the pending folds (ig_conv_bwd, fold_plain) in one launch per 64 of them -- behind the weight-gradient
+// launches on their stream (the caller joins the streams afterwards)
+int ig_finish_wgrad(Model* m) {
+    auto it = g_ig.find(m);
+    if (it == g_ig.end() || it->second.fold_pending.empty()) return DNNCA_OK;
+    IgPlan& pl = it->second;
+    const size_t n = pl.fold_pending.size(), nchunks = (n + ig::kFoldBatch - 1) / ig::kFoldBatch;
+    std::vector<int> first(nchunks * ig::kFoldBatch, 0), grid(nchunks, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const ig::FoldSeg& f = pl.fold_pending[i];
+        const int floats = 9 * f.cs * f.cout + f.n_b;
+        first[i] = grid[i / ig::kFoldBatch];
+        grid[i / ig::kFoldBatch] += f.g16 ? (floats + 63) / 64 : (floats + 1023) / 1024;
+    }
+    if (!m->dry) {
+        const bool same = pl.fold_on_dev.size() == n && memcmp(pl.fold_on_dev.data(), pl.fold_pending.data(), n * sizeof(ig::FoldSeg)) == 0;
+        if (!same) {
+            HIP_TRY(hipDeviceSynchronize());          // the previous step's fold may still be reading the tables
+            if (pl.fold_cap < nchunks * ig::kFoldBatch) {
+                pl.fold_cap = nchunks * ig::kFoldBatch;
+                DN_TRY(m->alloc((void**)&pl.fold_dev, pl.fold_cap * sizeof(ig::FoldSeg)));
+                DN_TRY(m->alloc((void**)&pl.fold_first_dev, pl.fold_cap * sizeof(int)));
+                HIP_TRY(hipStreamSynchronize(m->stream));          // (alloc clears on the stream)
+            }
+            HIP_TRY(hipMemcpy(pl.fold_dev, pl.fold_pending.data(), n * sizeof(ig::FoldSeg), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(pl.fold_first_dev, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+            pl.fold_on_dev = pl.fold_pending;
+        }
+    }
+    hipStream_t main_stream = m->stream;
+    if (m->wg_pending && m->wg_stream) m->stream = m->wg_stream;
+    for (size_t c = 0; c < nchunks; ++c) {
+        const int ns = (int)std::min<size_t>(ig::kFoldBatch, n - c * ig::kFoldBatch);
+        LAUNCH(m, "wg_fold_all", pl.fold_bytes / nchunks, 0,
+               hipLaunchKernelGGL(ig::k_wg_fold_batch, dim3(grid[c]), dim3(256), 0, m->stream, pl.fold_dev + c * ig::kFoldBatch,
+                                  pl.fold_first_dev + c * ig::kFoldBatch, ns));
+    }
+    m->stream = main_stream;
+    pl.fold_pending.clear();
+    pl.fold_bytes = 0;
+    return DNNCA_OK;
 }
 
 bool ig_tconv_supported(const Model* m, const Op& o) {

@@ -829,6 +829,7 @@ int Model::loss_and_backward(const float* y_dev, int B, const dnnca_loss_cfg& cf
                 }
             }
         }
+        DN_TRY(ig_finish_wgrad(this));
         DN_TRY(wg_side_join());
         DN_TRY(fast_finish_backward(this));
         if (desc.l2 > 0.f) {

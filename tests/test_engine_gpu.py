@@ -301,6 +301,44 @@ def test_dense_configs_at_real_widths_against_oracle(gpu, arch, C, opts, B, size
     m.close()
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_weight_gradient_slab_folds_per_launch_and_batched(gpu, monkeypatch, dtype):
+    """The atomics-free weight gradients (WgArgs::plain: every block stores its sums into its own slab) reach the gradient vector
+    through one fold launch behind each weight-gradient launch (default) or through ONE fold launch for the whole backward pass
+    (DNNCA_FOLD_BATCH=1, opt-in: k_wg_fold_batch finds its segment by a ballot over the segment table).  Same sums in the same order
+    either way: the gradients must agree to the noise of the BatchNorm statistics' double atomics and the transposed convs' float
+    atomics (1e-5 of each tensor's scale); the default arm is compared with the float64 oracle by the dense tests."""
+    opts = dict(n_filters_first=64, n_downsample=2, rate=2, kernel_size=3, conv_stride=1, bn=True, padding='same')
+    B, S = 2, 64
+    spec = O.ModelSpec('unet', 1, **opts)
+    rng = np.random.default_rng(11)
+    x = rng.random((B, S, S, 1)).astype(np.float32)
+    y = (rng.random((B, S, S)) < 0.05).astype(np.float32)
+    grads, plans = {}, {}
+    for arm in ('per_launch', 'batched'):
+        monkeypatch.delenv('DNNCA_FOLD_BATCH', raising=False)
+        if arm == 'batched':
+            monkeypatch.setenv('DNNCA_FOLD_BATCH', '1')
+        m = gpu.DeviceModel('unet', 1, S, S, B, dtype=dtype, **opts)
+        m.init_glorot(seed=4)
+        cfg = m.loss_cfg(weight_mul=3.0)
+        m.train_step(x, y, 0.0, cfg)
+        m.train_step(x, y, 0.0, cfg)          # the second step reuses the device-side segment table of the first
+        grads[arm] = m.get_grads().astype(np.float64)
+        plans[arm] = [r[0] for r in m.plan()]
+        m.close()
+    assert plans['per_launch'].count('wg_fold') >= 4 and 'wg_fold_all' not in plans['per_launch'], plans['per_launch']
+    assert plans['batched'].count('wg_fold_all') == 1 and 'wg_fold' not in plans['batched'], plans['batched']
+    ref = grads['per_launch']
+    assert np.isfinite(ref).all()
+    for name, sl in Hp.tensor_slices(spec):
+        if name in Hp.degenerate_tensors(spec):          # (biases in front of a BatchNorm: gradient = rounding noise around zero)
+            continue
+        scale = np.abs(ref[sl]).max()
+        err = np.abs(grads['batched'][sl] - ref[sl]).max()
+        assert scale > 0 and err <= 1e-5 * scale, (name, err / scale)
+
+
 def test_batchnorm_reductions_fold_themselves_repeatably(gpu):
     """The BatchNorm reductions add their partial sums to a small table with double atomics and the last block of the same launch
     folds it and leaves it zeroed (csrc/bn_dev.h).  A hundred steps at learning rate 0 on one model: every step finds the table zeroed (a
