@@ -112,4 +112,30 @@ __device__ __forceinline__ void bn_self_fold(const BnSelfFold& f, unsigned nbloc
     }
 }
 
+// The sums of a BatchNorm BACKWARD (dgamma = sum dy xhat, dbeta = sum dy) folding themselves the same way: the contributors (the
+// reduction pass k_bn_bwd_reduce_fast, or the data-gradient launch that produces dy: ConvArgs::bnb) add to bucket rows laid out
+// [C sums of dy xhat | C sums of dy]; the block that draws the last ticket adds the folded rows to dgamma / dbeta.
+struct BnBwdFold {
+    double* tab;             // nullptr: not wanted
+    unsigned* ticket;
+    int R, C;
+    float* dgamma;
+    float* dbeta;
+    const float* x;          // the BatchNorm's input (what xhat is made of), same layout as dy; contributors that are not the reduction pass
+    const float* coef;       // the BatchNorm's [4][C] coefficients: mean at 2C, 1 / sqrt(var + eps) at 3C
+};
+
+// All threads of every block call this once, after the block's last bucket add.
+__device__ __forceinline__ void bn_bwd_self_fold(const BnBwdFold& f, unsigned nblocks, unsigned bid) {
+    if (!bn_last_block(f.ticket, nblocks, bid)) return;
+    const int C = f.C, R = f.R;
+    for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) {
+        float* dst = o < C ? f.dgamma + o : f.dbeta + (o - C);
+        const float before = *dst;          // requested together with the rows: one memory round trip
+        const double a = bn_fold_column(f.tab, R, 2 * C, o);
+        for (int r = 0; r < R; ++r) f.tab[(size_t)r * 2 * C + o] = 0.0;
+        *dst = before + (float)a;
+    }
+}
+
 }  // namespace dnnca

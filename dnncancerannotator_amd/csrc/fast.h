@@ -78,15 +78,21 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
 // will this conv's forward and weight-gradient launches (batch B) be the kernels that can normalise a BatchNorm's input while staging it?
 bool ig_norm_on_load_ok(const Model* m, int B, const Op& o);
 struct BnSelfFold;
+struct BnBwdFold;
 // batch statistics of BatchNorm `bn` folded by the kernel that produces its input (bn_dev.h): fills *f and marks the statistics as
 // taken care of (Op::fused_stats_rows); false: not available (the BatchNorm then runs its own reduction pass)
 bool bn_self_fold_args(Model* m, Op& bn, int B, BnSelfFold* f);
+bool bn_bwd_fold_args(Model* m, Op& bn, BnBwdFold* f);      // the BatchNorm backward sums ride in the launch that produces dy (ConvArgs::bnb)
 // kernels_ig3x.hip: the fp32 3x3 convs on the bf16 matrix pipe (three bf16 planes per operand, fp32-accurate)
 namespace ig { struct ConvArgs; struct WgArgs; }
 bool ig3x_enabled(const Model* m);
 int ig3x_prepare(Model* m);
 void ig3x_release(Model* m);
-bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, const char* name, double bytes, double flops);
+bool ig3x_accepts(Model* m, const ig::ConvArgs& a, int cout);
+int ig3x_max_bnb_channels();
+// bnb_rode: (data gradient with ConvArgs::bnb filled) did the chosen kernel take the BatchNorm backward sums along?
+bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, const char* name, double bytes, double flops,
+                 bool* bnb_rode = nullptr);
 bool ig3x_wgrad_launch(Model* m, ig::WgArgs w, int co, const char* name, double bytes, double flops);
 int ig3x_wgrad_psplit(const Model* m, const ig::WgArgs& w, int co);      // pixel-split blocks of that launch; 0: not this path
 bool ig_tconv_supported(const Model* m, const Op& o);

@@ -50,6 +50,10 @@ struct ConvArgs {
     int src_half;            // the sources are stored as bf16 (View::h; k_igb_conv3 only)
     int dst_half;            // forward, persistent kernels: dst[0] is stored as bf16 (the input of a BatchNorm, ig_plan_half)
     int dsth[2];             // data gradient, persistent kernels: dst[k] is stored as bf16 (the gradient arriving at a BatchNorm)
+    // data gradient, k_ig3x_conv3: dst[0] (the only destination, neither accumulated nor masked) is ALL of the gradient arriving at a
+    // BatchNorm: that BatchNorm's backward sums (sum dy xhat, sum dy) ride in the epilogue, which reads the BatchNorm's input at the
+    // pixels it stores, and fold themselves (bn_dev.h; bnb.tab == nullptr: none) -- the BatchNorm's reduction pass is not launched
+    BnBwdFold bnb;
 };
 
 // Epilogue of the persistent kernels (k_ig_conv3 / igb::k_igb_conv3), straight from the accumulator registers: lane (m16, q)

@@ -126,9 +126,27 @@ __device__ __forceinline__ float row16_sum(float v) {
 // MODE 1 accumulate / act' mask / two destinations.  fp32 tensors only (the bf16-stored variants belong to dtype bf16).
 // WN > 1: the block's channel tile (16 NN WN channels from co0t) is split over WN groups of NWR row-waves: this wave (row group wave %
 // NWR, channel group wave / NWR) holds NN 16-channel tiles from co0t + 16 NN (wave / NWR).
+// MODE 2 (ConvArgs::bnb): the values of the BatchNorm's input at the pixels this lane will store, requested BEFORE the unit's last
+// MFMA phase -- loaded inside the epilogue, every unit paid one exposed HBM round trip (+13 us on a 512 x 512 x 16-channel launch).
+// Rows below the image and columns right of it read element 0 of their row's first pixel / of the tensor: never used.
+template <int NN, int NWR, int WN>
+__device__ __forceinline__ void bnb_prefetch(const ConvArgs& p, f32x4 (&z)[4][NN], int b, int y0, int x0, int co0t) {
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all % NWR, wn = wave_all / NWR, m16 = lane & 15, q = lane >> 4;
+    const int co0 = co0t + 16 * NN * wn, cw = p.n_dst0;
+    const int x = x0 + m16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + 4 * wave + r;
+        const bool in = y < p.H && x < p.W;
+        const unsigned o = in ? ((unsigned)(b * p.H + y) * (unsigned)p.W + (unsigned)x) * (unsigned)cw + (unsigned)(co0 + 4 * q) : (unsigned)(co0 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < NN; ++j) z[r][j] = *reinterpret_cast<const f32x4*>(p.bnb.x + o + 16 * j);
+    }
+}
+
 template <int NN, int MODE, int NWR, int WN = 1>
 __device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)[4][NN], int b, int y0, int x0, int co0t, int tile, float* red,
-                                           const float* bias_lds) {
+                                           const float* bias_lds, const f32x4 (&zpre)[4][MODE == 2 ? NN : 1]) {
     constexpr int COT = 16 * NN;
     const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all % NWR, wn = wave_all / NWR, m16 = lane & 15, q = lane >> 4;
     const int co0 = co0t + COT * wn;
@@ -136,6 +154,7 @@ __device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)
     const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co0 - p.n_dst0 : co0;
     float* dst = p.dst[which];
     const bool bn_on = MODE == 0 && p.bnf.tab != nullptr;
+    constexpr bool bb_on = MODE == 2;          // (one destination, neither accumulated nor masked; mean / inv in bias_lds)
     f32x4 bias[NN], bs[NN], bq[NN];
 #pragma unroll
     for (int j = 0; j < NN; ++j) {
@@ -168,6 +187,20 @@ __device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)
                     *reinterpret_cast<f32x4*>(dst + o + 16 * j) = t;
                 }
             }
+        } else if (bb_on) {          // the BatchNorm backward sums of the gradient this launch produces (ConvArgs::bnb)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                const f32x4 t = acc[r][j];
+                const f32x4 (&z)[MODE == 2 ? NN : 1] = zpre[r];
+                const f32x4 mean = *reinterpret_cast<const f32x4*>(bias_lds + co0 + 16 * j + 4 * q);
+                const f32x4 inv = *reinterpret_cast<const f32x4*>(bias_lds + cw + co0 + 16 * j + 4 * q);
+                if (okx) {
+                    bs[j] += t;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bq[j][i] = fmaf(t[i], (z[MODE == 2 ? j : 0][i] - mean[i]) * inv[i], bq[j][i]);      // as k_bn_bwd_reduce_fast
+                    *reinterpret_cast<f32x4*>(dst + o + 16 * j) = t;
+                }
+            }
         } else {
             f32x4 t[NN], old[NN], mk[NN];
 #pragma unroll
@@ -187,12 +220,12 @@ __device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)
             }
         }
     }
-    if (bn_on) {        // this unit's sums go to bucket row tile % R: [2 cw], first half sums, second half sums of squares
+    if (bn_on || bb_on) {        // this unit's sums go to bucket row tile % R: [2 cw], forward: sums | sums of squares; backward: sums of dy xhat | sums of dy
 #pragma unroll
         for (int j = 0; j < NN; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float s1 = row16_sum(bs[j][i]), s2 = row16_sum(bq[j][i]);
+                const float s1 = row16_sum(MODE == 0 ? bs[j][i] : bq[j][i]), s2 = row16_sum(MODE == 0 ? bq[j][i] : bs[j][i]);
                 if (m16 == 0) {
                     red[wave_all * (2 * COT) + 16 * j + 4 * q + i] = s1;
                     red[wave_all * (2 * COT) + COT + 16 * j + 4 * q + i] = s2;
@@ -206,12 +239,14 @@ __device__ __forceinline__ void epilogue_t(const ConvArgs& p, const f32x4 (&acc)
             for (int w = 0; w < NWR; ++w) a += red[(g * NWR + w) * (2 * COT) + e];
             const int half = e >= COT, c = half ? e - COT : e;
             // (all channel groups of a block go to the same destination: a channel tile never straddles the two destinations)
-            atomicAdd(bn_bucket(p.bnf, tile) + half * cw + (cl - COT * wn) + COT * g + c, (double)a);
+            double* row = MODE == 0 ? bn_bucket(p.bnf, tile) : p.bnb.tab + (size_t)(tile % p.bnb.R) * 2 * p.bnb.C;
+            atomicAdd(row + half * cw + (cl - COT * wn) + COT * g + c, (double)a);
         }
     }
 }
 
-// MODE 0 forward, MODE 1 data gradient (the forward kernel on the flipped / transposed planes).  w3: the conv's plane 0,
+// MODE 0 forward, MODE 1 data gradient (the forward kernel on the flipped / transposed planes), MODE 2 data gradient whose epilogue also
+// takes the backward sums of the BatchNorm in front of the conv (ConvArgs::bnb: one destination, neither accumulated nor masked).  w3: the conv's plane 0,
 // [9][N channels][K channels] bf16 with K contiguous; planes 1, 2 at + pstride, + 2 pstride elements.
 // NW waves: 4 -> 16 x 16-pixel tiles (one wave per SIMD), 8 -> 32 x 16 (two per SIMD).  Channel tile 16 NN.
 // WN = 2 (NW = 8 only): 16 x 16-pixel tiles like NW = 4, the eight waves are 4 row groups x 2 channel halves (8 NN channels... 16 NN / 2 each):
@@ -235,18 +270,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
     __shared__ float bn_red[NW * 2 * 16 * NJ];       // cross-wave fold of the fused BatchNorm statistics (epilogue_t)
     // the bias vector, read by the epilogue through LDS: a global load there queues behind the next item's prefetch (vmcnt retires in
     // order) and cost the epilogue of a 16-channel unit 4 k cycles of waiting (tools/x3_stamps.py)
-    __shared__ __attribute__((aligned(16))) float bias_lds[MODE == 0 ? kMaxBias : 4];
+    // (data gradient with ConvArgs::bnb: the BatchNorm's mean and 1 / sigma instead, [n_dst0] each)
+    __shared__ __attribute__((aligned(16))) float bias_lds[MODE == 1 ? 4 : kMaxBias];
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % NWR, wn = (tid >> 6) / NWR;          // row group, channel half
     const int m16 = lane & 15, q = lane >> 4;
     const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
     if (MODE == 0)
         for (int c = tid; c < nout; c += NT) bias_lds[c] = p.bias ? p.bias[c] : 0.f;          // (visible behind the first item's barrier)
+    else if (MODE == 2)
+        for (int c = tid; c < 2 * nout; c += NT) bias_lds[c] = p.bnb.coef[2 * nout + c];      // [mean | inv] of the [4][C] table, C = nout
     const int nco = nout / COT, ntiles = p.tiles_x * p.tiles_y * p.B, nunits = ntiles * nco;
     const int nchunks = kin / KC;
     const bool xcd_map = (ntiles & 7) == 0 && (gridDim.x & 7) == 0;
     const int my_units = (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     if (my_units <= 0) {          // (the launcher sizes the grid to the units: not reached)
         if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);
+        if (MODE == 2) bn_bwd_self_fold(p.bnb, gridDim.x, blockIdx.x);
         return;
     }
 
@@ -431,6 +470,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
     const bf16_t* bP[3] = {b_base, b_base + BPL, b_base + (hA ? 0 : 2 * BPL)};          // (b0 | b0), (b1 | b1), (b2 | b0)
 
     f32x4 acc[4][NJ];
+    f32x4 zpre[4][MODE == 2 ? NJ : 1];          // MODE 2: bnb_prefetch
     if constexpr (DB) {
         static_assert(AU + BU <= 12, "staging slices of the 27 MFMA steps");
         // prologue: item 0 into buffer 0, item 1 into the registers
@@ -470,6 +510,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
                 bf16_t* other = lds + ((it & 1) ^ 1) * BUF;
                 const Stage nx = next_stage();                        // item it + 2
                 if (norm_any) stage_coef(nx, n_sc_nxt, n_sh_nxt);     // used by the NEXT item's commits
+                if constexpr (MODE == 2) {
+                    if (chunk == nchunks - 1) {
+                        const Unit uz = unit_of(k);
+                        bnb_prefetch<NJ, NWR, WN>(p, zpre, uz.b, uz.y0, uz.x0, uz.co0);
+                    }
+                }
                 bf16x8 fa[2][6], fb[2][NJ];
                 auto load_a = [&](bf16x8 (&a)[6], const bf16_t* base, int g) {
 #pragma unroll
@@ -516,9 +562,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
                 lds_barrier();
             }
             const Unit u = unit_of(k);
-            epilogue_t<NJ, MODE, NWR, WN>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red, bias_lds);
+            epilogue_t<NJ, MODE, NWR, WN>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red, bias_lds, zpre);
         }
         if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);
+        if (MODE == 2) bn_bwd_self_fold(p.bnb, gridDim.x, blockIdx.x);
         return;
     }
     issue_item(next_stage());
@@ -539,6 +586,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
             // the next item's loads: issued BEHIND the barrier -- their address arithmetic (1 - 3 k cycles per item in front of it,
             // tools/x3_stamps.py) then runs beside the other waves' MFMAs instead of holding the whole block up
             issue_item(next_stage());
+            if constexpr (MODE == 2) {
+                if (chunk == nchunks - 1) {
+                    const Unit uz = unit_of(k);
+                    bnb_prefetch<NJ, NWR, WN>(p, zpre, uz.b, uz.y0, uz.x0, uz.co0);
+                }
+            }
             X3STAMP(it, 3);
             // 27 steps of 4 NN MFMAs: dx-major (g), per g first the (a0 | a1) fragments against (b0 | b0) and (b1 | b1) for the three dy taps,
             // then the (a0 | a2) fragments against (b2 | b0).  Two register sets for both operands: the LDS reads of the NEXT step (B) and
@@ -584,10 +637,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NN <= 2) ? 2 : 1) void k_ig3x_
             X3STAMP(it, 5);
         }
         const Unit u = unit_of(k);
-        epilogue_t<NJ, MODE, NWR, WN>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red, bias_lds);
+        epilogue_t<NJ, MODE, NWR, WN>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red, bias_lds, zpre);
         X3STAMP(it - 1, 6);
     }
     if (MODE == 0 && p.bnf.tab) bn_self_fold(p.bnf, gridDim.x, blockIdx.x);          // block-uniform; every block gets here
+    if (MODE == 2) bn_bwd_self_fold(p.bnb, gridDim.x, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -888,12 +942,22 @@ int ig3x_prepare(Model* m) {
 // channel tiles of 16 nn; false: not this path (the caller goes on to the exact-fp32 kernels).
 // Wave layout: eight waves on 32 x 16-pixel tiles while that gives every CU a unit; else (nn >= 2) eight waves on 16 x 16 tiles, split
 // 4 row groups x 2 channel halves; else four waves on 16 x 16 tiles.  DNNCA_IG_NW=4|8 forces the first / last (tuning aid, tests).
-bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, const char* name, double bytes, double flops) {
+// would ig3x_launch take this conv?  (ig_conv_bwd asks before it hands the BatchNorm backward sums to the launch: ConvArgs::bnb)
+bool ig3x_accepts(Model* m, const ig::ConvArgs& a, int cout) {
     if (!ig3x_enabled(m)) return false;
     Ig3xPlan& pl = g_ig3x[m];
     if (!m->dry && (!pl.wf || !pl.wd)) return false;
     if (a.src_half || a.dst_half || a.dsth[0] || a.dsth[1] || cout > ig3x::kMaxBias) return false;          // bf16-stored tensors: dtype bf16 only
     if (9.0 * cout * (a.c_src0 + a.c_src1) + 2.0 * pl.pstride > 1.0e9) return false;          // 32-bit byte offsets into the planes
+    return true;
+}
+int ig3x_max_bnb_channels() { return ig3x::kMaxBias / 2; }          // mean and 1 / sigma share the bias table
+
+bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int cout, int nn, const char* name, double bytes, double flops,
+                 bool* bnb_rode) {
+    if (bnb_rode) *bnb_rode = false;
+    if (!ig3x_accepts(m, a, cout)) return false;
+    Ig3xPlan& pl = g_ig3x[m];
     static const int forced = getenv("DNNCA_IG_NW") ? atoi(getenv("DNNCA_IG_NW")) : 0;
     static const bool no_split = getenv("DNNCA_X3_NO_SPLIT") != nullptr;          // tuning aid
     static const bool no_db = getenv("DNNCA_X3_NO_DB") != nullptr;                // tuning aid / A-B arm
@@ -913,22 +977,30 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
     a2.tiles_y = (a.H + rows - 1) / rows;
     const unsigned units = (unsigned)(a2.tiles_x * a2.tiles_y * a2.B * (cout / (16 * nn)));
     typedef void (*Kern)(ig::ConvArgs, const ig3x::bf16_t*, unsigned);
-    // [mode][nn index][layout: 4 waves, 8 waves, 8 waves split]
-    static const Kern kerns[2][3][3] = {
+    // [mode: forward, data gradient, data gradient + BatchNorm backward sums][nn index][layout: 4 waves, 8 waves, 8 waves split]
+    // (no <4, 2, 8>: that layout has no registers left for the sums -- such launches leave them to the BatchNorm's reduction pass)
+    static const Kern kerns[3][3][3] = {
         {{ig3x::k_ig3x_conv3<1, 0, 4>, ig3x::k_ig3x_conv3<1, 0, 8>, nullptr},
          {ig3x::k_ig3x_conv3<2, 0, 4>, ig3x::k_ig3x_conv3<2, 0, 8>, ig3x::k_ig3x_conv3<2, 0, 8, 2>},
          {ig3x::k_ig3x_conv3<4, 0, 4>, ig3x::k_ig3x_conv3<4, 0, 8>, ig3x::k_ig3x_conv3<4, 0, 8, 2>}},
         {{ig3x::k_ig3x_conv3<1, 1, 4>, ig3x::k_ig3x_conv3<1, 1, 8>, nullptr},
          {ig3x::k_ig3x_conv3<2, 1, 4>, ig3x::k_ig3x_conv3<2, 1, 8>, ig3x::k_ig3x_conv3<2, 1, 8, 2>},
-         {ig3x::k_ig3x_conv3<4, 1, 4>, ig3x::k_ig3x_conv3<4, 1, 8>, ig3x::k_ig3x_conv3<4, 1, 8, 2>}}};
+         {ig3x::k_ig3x_conv3<4, 1, 4>, ig3x::k_ig3x_conv3<4, 1, 8>, ig3x::k_ig3x_conv3<4, 1, 8, 2>}},
+        {{ig3x::k_ig3x_conv3<1, 2, 4>, ig3x::k_ig3x_conv3<1, 2, 8>, nullptr},
+         {ig3x::k_ig3x_conv3<2, 2, 4>, ig3x::k_ig3x_conv3<2, 2, 8>, ig3x::k_ig3x_conv3<2, 2, 8, 2>},
+         {ig3x::k_ig3x_conv3<4, 2, 4>, nullptr, ig3x::k_ig3x_conv3<4, 2, 8, 2>}}};
     const int ni = nn == 4 ? 2 : (nn == 2 ? 1 : 0), li = wn == 2 ? 2 : (nw == 8 ? 1 : 0);
-    static const Kern kerns_db[2][2] = {{ig3x::k_ig3x_conv3<1, 0, 8, 1, true>, ig3x::k_ig3x_conv3<2, 0, 8, 2, true>},
-                                        {ig3x::k_ig3x_conv3<1, 1, 8, 1, true>, ig3x::k_ig3x_conv3<2, 1, 8, 2, true>}};
-    const Kern kern = db ? kerns_db[mode ? 1 : 0][ni] : kerns[mode ? 1 : 0][ni][li];
+    static const Kern kerns_db[3][2] = {{ig3x::k_ig3x_conv3<1, 0, 8, 1, true>, ig3x::k_ig3x_conv3<2, 0, 8, 2, true>},
+                                        {ig3x::k_ig3x_conv3<1, 1, 8, 1, true>, ig3x::k_ig3x_conv3<2, 1, 8, 2, true>},
+                                        {ig3x::k_ig3x_conv3<1, 2, 8, 1, true>, ig3x::k_ig3x_conv3<2, 2, 8, 2, true>}};
+    int mi = mode ? 1 : 0;
+    if (mode == 1 && a.bnb.C > 0 && (db ? kerns_db[2][ni] : kerns[2][ni][li]) != nullptr) mi = 2;
+    if (bnb_rode) *bnb_rode = mi == 2;
+    const Kern kern = db ? kerns_db[mi][ni] : kerns[mi][ni][li];
     // a persistent kernel's grid is the number of blocks that are resident at once: several per CU where LDS and registers allow
     // (a block alternates between committing an item and running its MFMAs; co-resident blocks fill each other's commit phases)
-    static int occ[2][3][4] = {};
-    int& oc = occ[mode ? 1 : 0][ni][db ? 3 : li];
+    static int occ[3][3][4] = {};
+    int& oc = occ[mi][ni][db ? 3 : li];
     if (oc == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64 * nw, 0) != hipSuccess || nb < 1) nb = 1;
@@ -939,7 +1011,7 @@ bool ig3x_launch(Model* m, int mode, const ig::ConvArgs& a, size_t w_off, int co
     const unsigned resident = 256u * (unsigned)oc;
     const unsigned g = units < resident ? units : resident;
     const ig3x::bf16_t* w3 = (mode == 0 ? pl.wf : pl.wd) + w_off;
-    m->set_variant("x3n%dw%d%s%s", nn, nw, wn == 2 ? "s" : "", db ? "d" : "");
+    m->set_variant("x3n%dw%d%s%s%s", nn, nw, wn == 2 ? "s" : "", db ? "d" : "", mi == 2 ? "b" : "");      // b: BatchNorm backward sums ride
     LAUNCH(m, name, bytes, flops, hipLaunchKernelGGL(kern, dim3(g), dim3(64 * nw), 0, m->stream, a2, w3, pl.pstride));
     return true;
 }

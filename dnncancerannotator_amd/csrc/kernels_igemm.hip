@@ -2488,14 +2488,15 @@ static int ig_waves(const ig::ConvArgs& a, int cout) {
 }
 
 template <int MODE>
-static void launch_ig(Model* m, const ig::ConvArgs& a, size_t w_off, int cout, const char* name, double bytes, double flops) {
+static void launch_ig(Model* m, const ig::ConvArgs& a, size_t w_off, int cout, const char* name, double bytes, double flops, bool* bnb_rode = nullptr) {
+    if (bnb_rode) *bnb_rode = false;
     {   // pipelined persistent kernel: channel tile 16 nn3 must divide both destinations; 32-bit byte offsets
         const int nn3 = ig_nn3(a);
         if (conv3_path(a, cout, false)) {
             static const int x3_nn_cap = getenv("DNNCA_X3_NN") ? atoi(getenv("DNNCA_X3_NN")) : 4;          // tuning aid: channel tile at most 16 x this
             const int nnx = nn3 > x3_nn_cap && (x3_nn_cap == 1 || x3_nn_cap == 2) ? x3_nn_cap : nn3;
             // fp32 by three bf16 planes on the bf16 matrix pipe (kernels_ig3x.hip), unless switched off
-            if (ig3x_launch(m, MODE, a, w_off, cout, nnx, MODE == 0 ? "ig3x_conv_fwd" : "ig3x_conv_dgrad", bytes, flops))
+            if (ig3x_launch(m, MODE, a, w_off, cout, nnx, MODE == 0 ? "ig3x_conv_fwd" : "ig3x_conv_dgrad", bytes, flops, bnb_rode))
                 return;
             if (MODE == 1) {          // declined although the plan expected it: this conv's flipped weights were not made at ig_begin_backward
                 IgPlan& plz = g_ig[m];
@@ -2778,10 +2779,25 @@ bool ig_conv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, doub
             a.B = B; a.H = o.out.d.H; a.W = o.out.d.W;
             a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.alpha = o.mask_alpha;
+            // this launch writes ALL of the gradient arriving at the BatchNorm that feeds the conv (its only reader, nothing accumulated,
+            // no act' mask): the BatchNorm's backward sums ride in the epilogue and its reduction pass is not launched (ConvArgs::bnb;
+            // split-bf16 kernel, f32 tensors)
+            static const bool no_bnb = getenv("DNNCA_NO_BN_BWD_RIDE") != nullptr;          // A/B
+            Op* bnb_op = nullptr;
+            if (!no_bnb && !use_bf16(m, o) && CB == 0 && o.src_bn[0] >= 0 && !o.accA && !o.maskA && CA <= ig3x_max_bnb_channels()) {
+                Op& bn = m->ops[o.src_bn[0]];
+                const bool sole = bn.out_readers.size() == 1 && bn.out_readers[0] == (int)(&o - m->ops.data());
+                if (sole && bn.out.g.p == o.inA.g.p && bn.out.g.C == CA && conv3_path(a, CA, false) && ig3x_accepts(m, a, CA) &&
+                    bn_bwd_fold_args(m, bn, &a.bnb))
+                    bnb_op = &bn;
+            }
             if (use_bf16(m, o))
                 launch_igb<1>(m, a, pl.wd + o.w_off, CA + CB, "igb_conv_dgrad", out_bytes + in_bytes, flops);
-            else
-                launch_ig<1>(m, a, o.w_off, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops);
+            else {
+                bool rode = false;
+                launch_ig<1>(m, a, o.w_off, CA + CB, "ig_conv_dgrad", out_bytes + in_bytes, flops, &rode);
+                if (bnb_op && !rode) bnb_op->bwd_sums_rode = false;          // (a layout without the sums: the reduction pass runs as before)
+            }
         }
     };
     // the fork sits in front of the data gradient (measured: forking behind it, so that the weight gradient meets only the next

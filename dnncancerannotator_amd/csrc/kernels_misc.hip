@@ -865,14 +865,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
     // ticket: a block's adds have been performed (device-scope atomics, each thread waits vmcnt(0) for its own in bn_last_block, then
     // the barrier) before its ticket is drawn; the last block reads the rows with device-scope loads.  No device-scope FENCE anywhere: on gfx950 that is an L2 write-back / invalidate per block,
     // and 512 of them cost more than the reduction (74 us against 25); nothing here is published through plain stores.
-    if (!bn_last_block(ticket, gridDim.x, blockIdx.x)) return;
-    for (int o = threadIdx.x; o < 2 * C; o += 256) {
-        float* dst = o < C ? dgamma + o : dbeta + (o - C);
-        const float before = *dst;          // requested together with the rows: one memory round trip
-        const double a = bn_fold_column(tab, R, 2 * C, o);
-        for (int r = 0; r < R; ++r) tab[(size_t)r * 2 * C + o] = 0.0;
-        *dst = before + (float)a;
-    }
+    bn_bwd_self_fold(BnBwdFold{tab, ticket, R, C, dgamma, dbeta, nullptr, nullptr}, gridDim.x, blockIdx.x);
 }
 
 template <bool DH, bool XH, bool GH, int PG>      // DH: dx is stored as bf16 (never accumulated into); XH / GH: x / dy are; PG: see PoolGrad
@@ -1042,6 +1035,29 @@ bool fast_pool_into_bn(Model* m, Op& pool, Op& bn) {
     return true;
 }
 
+// The data-gradient launch that produces ALL of this BatchNorm's dy (a 3x3 conv that is the only reader of the BatchNorm's output)
+// takes the backward sums along in its epilogue (ConvArgs::bnb): fills `f` and marks the op so that fast_bn_bwd skips its reduction
+// pass.  f32 tensors; the caller has checked that it is the only writer of dy and clears Op::bwd_sums_rode if its kernel declines.
+bool bn_bwd_fold_args(Model* m, Op& bn, BnBwdFold* f) {
+    if (bn.type != OP_BN || !fast_bn_supported(m, bn) || bn.pool_grad || bn.inA.d.h || bn.out.g.h || bn.inA.g.h) return false;
+    if (bn.out.g.ps != bn.inA.d.C || dense_switches().no_bn_fusion) return false;
+    const int C = bn.inA.d.C;
+    f->C = C;          // (also in the dry run: the launch's variant name says that the sums ride)
+    if (!m->dry) {
+        if (!bn_table(m)) return false;
+        int R = Model::kBnTab / (2 * C);
+        f->tab = m->bn_tab;
+        f->ticket = reinterpret_cast<unsigned*>(m->bn_tab + Model::kBnTab);
+        f->R = R > kBnRows ? kBnRows : R;
+        f->dgamma = m->g + bn.w_off;
+        f->dbeta = m->g + bn.b_off;
+        f->x = bn.inA.d.p;
+        f->coef = bn.coef;
+    }
+    bn.bwd_sums_rode = true;
+    return true;
+}
+
 bool fast_bn_bwd(Model* m, int B, Op& o) {
     if (!bn_fast_ok(o.inA.d) || o.out.g.ps % 4 || o.inA.g.ps != o.inA.d.C) return false;
     const int C = o.inA.d.C;
@@ -1072,7 +1088,10 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
 #define BNRED(XHv, GHv, PGv) LAUNCH(m, "bn_bwd_reduce", rb, tb,                                                              \
         hipLaunchKernelGGL((k_bn_bwd_reduce_fast<XHv, GHv, PGv>), dim3(nb), dim3(256), 0, m->stream, npix, o.inA.d.p, o.out.g.p, C, \
                            o.out.g.ps, o.coef, m->bn_tab, R, ticket, m->g + o.w_off, m->g + o.b_off, pg))
-    if (pgm) {          // (fast_pool_into_bn: f32 tensors)
+    const bool rode = o.bwd_sums_rode;          // the launch that produced dy has left dgamma / dbeta (bn_bwd_fold_args)
+    o.bwd_sums_rode = false;
+    if (rode) {
+    } else if (pgm) {          // (fast_pool_into_bn: f32 tensors)
         if (pgm == 1) BNRED(false, false, 1); else BNRED(false, false, 2);
     } else if (xh) { if (gh) BNRED(true, true, 0); else BNRED(true, false, 0); }
     else { if (gh) BNRED(false, true, 0); else BNRED(false, false, 0); }

@@ -47,6 +47,8 @@ struct Op {
     // the pooled gradient themselves; pool_grad_acc: dy already holds another reader's gradient (a skip connection)
     const Op* pool_grad = nullptr;
     bool pool_grad_acc = false;
+    // BN: this step's dgamma / dbeta sums rode in the data-gradient launch that produced dy (bn_bwd_fold_args): no reduction pass
+    bool bwd_sums_rode = false;
     int src_bn[2] = {-1, -1};
     std::vector<int> out_readers;
     // pool: position (0..3, row-major in the 2x2 window) of each output's first maximum, written by the fused BN-apply + pool
