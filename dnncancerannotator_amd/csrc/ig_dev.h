@@ -194,6 +194,15 @@ __device__ __forceinline__ void conv3_epilogue(const ConvArgs& p, const f32x4 (&
     }
 }
 
+// sum over the 16 lanes of a DPP row (lanes that share q): quad swaps, then the two mirrors -- four v_add_f32 with DPP operands
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));     // row_mirror
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct WgArgs {
     const float* x;          // one source, dense NHWC, cs channels

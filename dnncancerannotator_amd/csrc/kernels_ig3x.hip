@@ -108,14 +108,7 @@ __global__ void k_ig3x_prep(const PrepDesc* __restrict__ descs, const float* __r
     }
 }
 
-// sum over the 16 lanes of a DPP row (lanes that share q): quad swaps, then the two mirrors -- four v_add_f32 with DPP operands
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));     // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));     // row_mirror
-    return v;
-}
+using ig::row16_sum;
 
 // Epilogue straight from the accumulators, CHANNEL-major: the MFMAs run with the operands swapped (rows = channels, columns =
 // pixels), so lane (m16, q) of wave w holds acc[r][j][i] = channel 16 j + 4 q + i of pixel (row 4 w + r, column m16): four

@@ -2007,6 +2007,161 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_fwd(TcArgs p, const bf16_t
     }
 }
 
+// forward, second generation (round 4; output stored as bf16): the same block tile (128 input pixels x 64 output channels x 4
+// parities, K chunks of 32) with what the first one lacked:
+//   * two LDS buffers and register prefetch -- chunk c + 1 goes to the other buffer and chunk c + 2's loads are issued while chunk c's
+//     MFMAs run: one barrier per chunk (the first version loaded, waited, multiplied, chunk after chunk); two blocks per CU, so one
+//     block's prologue and epilogue run beside the other's K loop;
+//   * eight waves = 2 output-row parities x 4 pixel quarters; the MFMAs run channel-major (rows = output channels: A = kernel rows;
+//     columns = pixels: B), so a lane holds four consecutive channels of a pixel;
+//   * the results (bias added, rounded) pass a wave-private LDS tile laid out as the output is -- [pixel][column parity][64 channels]
+//     -- and leave as 16-byte stores, eight lanes per 128-byte run of 64 channels: full cache lines, 1 KB per store instruction.
+//     (Measured on the way, tuning builds: with 8-byte stores of four channels per lane -- 32-byte requests -- the stores ALONE took
+//     half of the full-resolution launch: the store path is bound by requests, not bytes.)
+//   * the batch statistics of the BatchNorm behind the layer (of the stored values) are DPP row sums over the 16 pixels of a tile.
+// What was also built and measured and is NOT here (NOTES.md, round-4 log 11): persistent blocks with the kernel chunk resident in
+// LDS, pixels straight from global memory as MFMA operands, pixel prefetch two items ahead behind the stores with hand-balanced
+// vmcnt counts -- 53.5 us against this kernel's at the full-resolution level, slower at the three deeper ones, three times the code.
+template <bool X16>      // X16: the input is stored as bf16
+__global__ __launch_bounds__(512, 2) void k_igb_tconv_fwd2(TcArgs p, const bf16_t* __restrict__ w16) {
+    constexpr int XB = 128 * RS, WB = 4 * 64 * RS, BUF = XB + WB;          // bf16 elements per buffer: 30 KB
+    constexpr int ORS = 128 + 8;                                            // output tile row: [e][64 channels] + pad (bf16)
+    static_assert(8 * 16 * ORS <= 2 * BUF, "the output tiles of one pixel half fit the staging buffers");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * BUF];
+    __shared__ float red[8 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int a = wave & 1, pq = wave >> 1;
+    const int p0 = blockIdx.x * 128, co0 = blockIdx.y * 64;
+    const int nchunks = p.cin / CK;
+    f32x4 acc[2][4][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) acc[e][mt][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging: X chunk = 128 pixels x 32 channels (thread: pixel tid / 4, eight channels), W chunk = 256 rows (ae, co) x 32 channels
+    // (thread: rows tid / 4 and 128 + tid / 4, eight channels)
+    const int spx = tid >> 2, part = tid & 3;
+    const bool px_ok = p0 + spx < p.npix;
+    u32x4 xr[X16 ? 1 : 2], wr[2];
+    auto issue = [&](int c) {
+        const int cc = c * CK;
+        const size_t xo = (size_t)(px_ok ? p0 + spx : 0) * p.cin + cc + 8 * part;
+        if constexpr (X16) {
+            xr[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.in) + xo);
+        } else {
+            xr[0] = *reinterpret_cast<const u32x4*>(p.in + xo);
+            xr[1] = *reinterpret_cast<const u32x4*>(p.in + xo + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = spx + 128 * u, ae = r >> 6, n = r & 63;
+            wr[u] = *reinterpret_cast<const u32x4*>(w16 + ((size_t)ae * p.cout + co0 + n) * p.cin + cc + 8 * part);
+        }
+    };
+    auto commit = [&](bf16_t* buf) {
+        u32x4 h;
+        if constexpr (X16) {
+            h = xr[0];
+        } else {
+            const f32x4 f0 = __builtin_bit_cast(f32x4, xr[0]), f1 = __builtin_bit_cast(f32x4, xr[1]);
+            bf16x8 t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t[i] = (bf16_t)f0[i]; t[4 + i] = (bf16_t)f1[i]; }
+            h = __builtin_bit_cast(u32x4, t);
+        }
+        if (!px_ok) h = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(buf + spx * RS + 8 * part) = h;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4*>(buf + XB + (spx + 128 * u) * RS + 8 * part) = wr[u];
+    };
+    issue(0);
+    commit(lds);
+    if (nchunks > 1) issue(1);
+    lds_barrier();
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        const bf16_t* buf = lds + (c & 1) * BUF;
+        bf16x8 xf[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) xf[pt] = *reinterpret_cast<const bf16x8*>(buf + (32 * pq + 16 * pt + m16) * RS + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(buf + XB + ((2 * a + e) * 64 + 16 * mt + m16) * RS + 8 * q);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) acc[e][mt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[pt], acc[e][mt][pt], 0, 0, 0);
+            }
+        if (c + 1 < nchunks) {
+            commit(lds + ((c + 1) & 1) * BUF);
+            if (c + 2 < nchunks) issue(c + 2);
+        }
+        lds_barrier();
+    }
+    // epilogue: lane (m16, q) holds channels co0 + 16 mt + 4 q .. + 3 of input pixel p0 + 32 pq + 16 pt + m16, row parity a, both
+    // column parities.  Per pixel half pt the wave writes its 16 pixels into its own tile [16][e][64] (the staging buffers are free:
+    // the loop ended on a barrier; a wave's DS operations execute in order) and stores it 16 bytes per lane
+    bf16_t* wt = lds + wave * (16 * ORS);
+    const FastDiv d_W(p.W);
+    f32x4 bias[4], bs[4], bq[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        bias[mt] = *reinterpret_cast<const f32x4*>(p.bias + co0 + 16 * mt + 4 * q);
+        bs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bq[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int pw = p0 + 32 * pq + 16 * pt;
+        const bool mine = pw + m16 < p.npix;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 v = acc[e][mt][pt] + bias[mt];
+                hbf16x4 h;          // the statistics are those of the stored values
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { h[i] = (hbf16)v[i]; v[i] = mine ? (float)h[i] : 0.f; }
+                *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(wt) + m16 * ORS + e * 64 + 16 * mt + 4 * q) = h;
+                bs[mt] += v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bq[mt][i] = fmaf(v[i], v[i], bq[mt][i]);
+            }
+        // word t of lane L: pixel 4 t + L / 16 of the 16, bf16 elements 8 (L % 16) .. of its [e][64 channels] row
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int px = pw + 4 * t + (lane >> 4);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wt + (4 * t + (lane >> 4)) * ORS + 8 * (lane & 15));
+            if (px < p.npix) {
+                const int bi = d_W.div(px), jx = px - bi * p.W;          // bi = b * H + i
+                const int l16 = lane & 15, e = l16 >> 3, ch = 8 * (l16 & 7);
+                const size_t o = (((size_t)bi * 2 + a) * (2 * p.W) + 2 * jx + e) * p.cout + co0 + ch;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + o) = v;
+            }
+        }
+    }
+    if (p.bnf.tab) {        // batch statistics for the BatchNorm behind the transposed conv: a bucket row per pixel block
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s1 = ig::row16_sum(bs[mt][i]), s2 = ig::row16_sum(bq[mt][i]);
+                if (m16 == 0) { red[wave * 128 + 16 * mt + 4 * q + i] = s1; red[wave * 128 + 64 + 16 * mt + 4 * q + i] = s2; }
+            }
+        __syncthreads();
+        if (tid < 128) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[w * 128 + tid];
+            const int half = tid >> 6, c = tid & 63;
+            atomicAdd(bn_bucket(p.bnf, (int)blockIdx.x) + half * p.cout + co0 + c, (double)sum);
+        }
+        bn_self_fold(p.bnf, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+    }
+}
+
 // data gradient: din[p][ci] = sum_{ae,co} dout[out(p,ae)][co] * W[ae][co][ci]; block = 128 pixels x 64 input channels,
 // K = 4 x Cout in chunks of 32; w16 = [ae][ci][co] (K = co contiguous)
 template <bool G16>      // G16: dout is stored as bf16
@@ -2447,6 +2602,7 @@ int ig_prepare(Model* m) {
 
 // once per backward pass: the data-gradient kernels read flipped/transposed weights
 int ig_begin_backward(Model* m) {
+    for (Op& o : m->ops) o.bwd_sums_rode = false;          // (a pass that stopped on an error may have left one set)
     if (m->desc.flags & 1) return DNNCA_OK;
     IgPlan& pl = g_ig[m];
     if (pl.n_eager == 0) return DNNCA_OK;
@@ -2886,6 +3042,15 @@ bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_nex
         if (bn_next && !dense_switches().no_bn_fusion)       // batch statistics of the BatchNorm behind it ride in the epilogue
             (void)bn_self_fold_args(m, *bn_next, B, &a.bnf);
         const dim3 grid((a.npix + 127) / 128, a.cout / 64);
+        static const bool gen1 = getenv("DNNCA_TCONV_FWD1") != nullptr;          // A/B: the first-generation kernel
+        if (!gen1 && a.out_half && (double)a.npix * 4.0 * a.cout < 2.0e9) {
+            m->set_variant("2h%d", (int)(o.inA.d.h != 0));
+            if (o.inA.d.h)
+                LAUNCH(m, "igb_tconv_fwd", bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_fwd2<true>, grid, dim3(512), 0, m->stream, a, pl.wf + o.w_off));
+            else
+                LAUNCH(m, "igb_tconv_fwd", bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_fwd2<false>, grid, dim3(512), 0, m->stream, a, pl.wf + o.w_off));
+            return true;
+        }
         m->set_variant("h%d", (int)(o.inA.d.h != 0));
         if (o.inA.d.h)
             LAUNCH(m, "igb_tconv_fwd", bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_fwd<true>, grid, dim3(256), 0, m->stream, a, pl.wf + o.w_off));
