@@ -1364,6 +1364,137 @@ constexpr int BUF3 = (PATCH2 + 9 * 64) * RS + 64;   // bf16 elements per LDS buf
 constexpr unsigned BUF_FLAGS = 0x00020000u;         // raw buffer descriptor word 3 (gfx9 family)
 constexpr unsigned OOB = 0x80000000u;               // beyond every tensor here: the buffer load returns zeros
 
+// Epilogue of k_igb_conv3 (round 4), CHANNEL-major: the MFMAs run with the operands swapped (rows = output channels, columns =
+// pixels), so lane (m16, q) of wave w holds acc[r][j][i] = channel 16 j + 4 q + i of pixel (row 4 w + r, column m16).  Same contract
+// as ig::conv3_epilogue (bias + activation + batch statistics of the stored values / accumulate, mask, two destinations).
+// bf16-STORED destinations (the normal case under dtype bf16) leave through a wave-private LDS tile: per tile row and 8-pixel half the
+// lanes of that half write their 64 channels (8-byte writes), then every lane reads 16 bytes and stores them -- eight lanes per
+// 128-byte run of a pixel's 64 channels, 1 KB per store instruction.  ig::conv3_epilogue stored one 2-byte value per lane and
+// instruction (64 store instructions per lane and unit, 32-byte requests): the store path is bound by requests, not bytes (measured on
+// k_igb_tconv_fwd2: the stores alone were half of a full-resolution launch).  otile: NW x [8 pixels][OTS]; wave w's first 512 bytes
+// double as its slot of the statistics fold.
+constexpr int OTS = 64 + 8;             // bf16 per pixel of the epilogue tile (144 B: the 8-byte writes of a half spread over the banks)
+template <int MODE, int NW>
+__device__ __forceinline__ void epilogue_cm(const ConvArgs& p, const f32x4 (&acc)[4][4], int b, int y0, int x0, int co0, int tile, bf16_t* otile) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int which = co0 >= p.n_dst0;
+    const int cw = which ? p.n_dst1 : p.n_dst0, cl = which ? co0 - p.n_dst0 : co0;
+    float* dst = p.dst[which];
+    const bool bn_on = MODE == 0 && p.bnf.tab != nullptr;
+    bf16_t* ot = otile + wave * (8 * OTS);
+    f32x4 bias[4], bs[4], bq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bias[j] = (MODE == 0 && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + co0 + 16 * j + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int x = x0 + m16;
+    const bool okx = x < p.W;
+    const bool half_out = MODE == 0 ? p.dst_half != 0 : (p.dsth[which] != 0 && !p.acc[which]);      // block-uniform: through the LDS tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + 4 * wave + r;
+        if (y >= p.H) continue;                 // wave-uniform
+        // element offset in 32 bits (the launcher checks that every destination has fewer than 2^32 elements)
+        const unsigned orow = (unsigned)(b * p.H + y) * (unsigned)p.W;
+        const unsigned o = (orow + (unsigned)(okx ? x : 0)) * (unsigned)cw + (unsigned)(cl + 4 * q);
+        if (half_out) {
+            hbf16x4 th[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 t = acc[r][j] + bias[j];
+                if (MODE == 0 && p.alpha >= 0.f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = t[i] > 0.f ? t[i] : p.alpha * t[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { th[j][i] = (hbf16)t[i]; t[i] = (float)th[j][i]; }      // the statistics are those of the stored values
+                if (bn_on && okx) {
+                    bs[j] += t;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bq[j][i] = fmaf(t[i], t[i], bq[j][i]);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if ((m16 >> 3) == h) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(ot) + (m16 & 7) * OTS + 16 * j + 4 * q) = th[j];
+                }
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + (lane >> 3) * OTS + 8 * (lane & 7));
+                const int xs = x0 + 8 * h + (lane >> 3);
+                if (xs < p.W)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(dst) + (size_t)((orow + (unsigned)xs) * (unsigned)cw + (unsigned)(cl + 8 * (lane & 7)))) = v;
+            }
+        } else if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 t = acc[r][j] + bias[j];
+                if (p.alpha >= 0.f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = t[i] > 0.f ? t[i] : p.alpha * t[i];
+                }
+                if (okx) {
+                    if (bn_on) {
+                        bs[j] += t;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) bq[j][i] = fmaf(t[i], t[i], bq[j][i]);
+                    }
+                    *reinterpret_cast<f32x4*>(dst + o + 16 * j) = t;
+                }
+            }
+        } else if (p.dsth[which]) {          // bf16 destination that accumulates (never masked: the BatchNorm backward applies act')
+            hbf16* dh = reinterpret_cast<hbf16*>(dst);
+            hbf16x4 oldh[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oldh[j] = okx ? *reinterpret_cast<const hbf16x4*>(dh + o + 16 * j) : hbf16x4{(hbf16)0.f, (hbf16)0.f, (hbf16)0.f, (hbf16)0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hbf16x4 th;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) th[i] = (hbf16)(acc[r][j][i] + (float)oldh[j][i]);
+                if (okx) *reinterpret_cast<hbf16x4*>(dh + o + 16 * j) = th;
+            }
+        } else {
+            f32x4 t[4], old[4], mk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[j] = acc[r][j];
+                if (p.acc[which]) old[j] = okx ? *reinterpret_cast<const f32x4*>(dst + o + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.mask[which]) mk[j] = okx ? *reinterpret_cast<const f32x4*>(p.mask[which] + o + 16 * j) : f32x4{1.f, 1.f, 1.f, 1.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (p.acc[which]) t[j] += old[j];
+                if (p.mask[which]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[j][i] *= mk[j][i] > 0.f ? 1.0f : p.alpha;
+                }
+                if (okx) *reinterpret_cast<f32x4*>(dst + o + 16 * j) = t[j];
+            }
+        }
+    }
+    if (bn_on) {        // this unit's sums go to bucket row tile % R: [2 cw], first half sums, second half sums of squares
+        float* red = reinterpret_cast<float*>(ot);          // the wave's 128-float slot (its tile is free: DS operations execute in order)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s1 = ig::row16_sum(bs[j][i]), s2 = ig::row16_sum(bq[j][i]);
+                if (m16 == 0) { red[16 * j + 4 * q + i] = s1; red[64 + 16 * j + 4 * q + i] = s2; }
+            }
+        lds_barrier();
+        if (tid < 128) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += reinterpret_cast<const float*>(otile + w * (8 * OTS))[tid];
+            const int half = tid >= 64, c = half ? tid - 64 : tid;
+            atomicAdd(bn_bucket(p.bnf, tile) + half * cw + cl + c, (double)a);
+        }
+    }
+}
+
 // A16: the sources are stored as bf16 (View::h): 16-byte loads of 8 channels go to LDS as they are.
 // NW: waves per block.  4: 16 x 16-pixel tiles, one wave per SIMD.  8: 32 x 16-pixel tiles, two waves per SIMD (256 registers
 // each) -- a single wave cannot issue v_mfma_f32_16x16x32_bf16 back to back (1.7 of 2.46 PFLOP/s, mfma_bf16_rate.hip), the
@@ -1378,7 +1509,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_igb_conv3(ConvArgs p, const
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(NW == 8 || BUFX == BUF3, "layout of the 4-wave kernel");
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * BUFX];
-    __shared__ float bn_red[NW * 2 * 64];       // cross-wave fold of the fused BatchNorm statistics (conv3_epilogue)
+    __shared__ __attribute__((aligned(16))) bf16_t otile[NW * 8 * OTS];      // epilogue_cm: wave-private output tiles + the statistics fold
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4;
     const int kin = p.c_src0 + p.c_src1, nout = p.n_dst0 + p.n_dst1;
@@ -1566,7 +1697,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_igb_conv3(ConvArgs p, const
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][r + dy], fb[s & (FB - 1)][j], acc[r][j], 0, 0, 0);
+                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s & (FB - 1)][j], fa[g & 1][r + dy], acc[r][j], 0, 0, 0);      // rows = channels, columns = pixels
             if (FB == 1 && s + 1 < 9) {
                 const int g1 = (s + 1) / 3, dy1 = (s + 1) % 3;
 #pragma unroll
@@ -1579,7 +1710,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_igb_conv3(ConvArgs p, const
     }
         {
             const Unit u = unit_of(k);
-            ig::conv3_epilogue<4, MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, bn_red);
+            epilogue_cm<MODE, NW>(p, acc, u.b, u.y0, u.x0, u.co0, u.tile, otile);
             IGSTAMP(it - 1, 7);
         }
     }
