@@ -835,6 +835,125 @@ __global__ __launch_bounds__(256) void k_ig_tconv_fwd(TcArgs p) {
         }
 }
 
+// forward, second generation (round 4): one block = 128 input pixels x 16 NCO output channels x ALL FOUR parities (the first one ran a
+// block per parity and re-read the pixels four times), two LDS buffers with register prefetch (chunk c + 2's loads fly during chunk
+// c's MFMAs: one barrier per chunk), MFMAs channel-major (rows = output channels: A = kernel rows; columns = pixels: B) so that a
+// lane holds four consecutive channels of a pixel -- 16-byte stores -- and the batch statistics of the BatchNorm behind the layer ride
+// along (DPP row sums over the 16 pixels of a tile, the self-folding table of bn_dev.h): no bn_stats launch.  Same fp32 MFMA chain per
+// output value as before (K ascending).
+template <int NCO>
+__global__ __launch_bounds__(256, 2) void k_ig_tconv_fwd2(TcArgs p) {
+    constexpr int COT = 16 * NCO, XB = 128 * CKP, WB = 4 * COT * CKP, BUF = XB + WB;          // floats per buffer
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    __shared__ float red[4 * 2 * COT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
+    const int p0 = blockIdx.x * 128, co0 = blockIdx.y * COT;
+    const int nchunks = p.cin / CK;
+    f32x4 acc[4][NCO][2];
+#pragma unroll
+    for (int ae = 0; ae < 4; ++ae)
+#pragma unroll
+        for (int mt = 0; mt < NCO; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) acc[ae][mt][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging: X chunk = 128 pixels x 16 channels = 512 float4 (two per thread); W chunk = 4 COT rows (ae, co) x 16 channels = 16 COT
+    // float4 (NCO per thread)
+    f32x4 xr[2], wr[NCO];
+    auto issue = [&](int c) {
+        const int cc = c * CK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, px = i >> 2, c4 = i & 3;
+            xr[u] = p0 + px < p.npix ? *reinterpret_cast<const f32x4*>(p.in + (size_t)(p0 + px) * p.cin + cc + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < NCO; ++u) {
+            const int i = tid + 256 * u, r = i >> 2, k4 = i & 3, ae = r / COT, n = r - ae * COT;
+            wr[u] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)ae * p.cout + co0 + n) * p.cin + cc + 4 * k4);
+        }
+    };
+    auto commit = [&](float* buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, px = i >> 2, c4 = i & 3;
+            *reinterpret_cast<f32x4*>(buf + px * CKP + 4 * c4) = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NCO; ++u) {
+            const int i = tid + 256 * u, r = i >> 2, k4 = i & 3;
+            *reinterpret_cast<f32x4*>(buf + XB + r * CKP + 4 * k4) = wr[u];
+        }
+    };
+    issue(0);
+    commit(lds);
+    if (nchunks > 1) issue(1);
+    lds_barrier();
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        const float* buf = lds + (c & 1) * BUF;
+#pragma unroll
+        for (int ks = 0; ks < CK / 4; ++ks) {
+            float xf[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) xf[pt] = buf[(32 * wave + 16 * pt + m16) * CKP + 4 * ks + q];
+#pragma unroll
+            for (int ae = 0; ae < 4; ++ae)
+#pragma unroll
+                for (int mt = 0; mt < NCO; ++mt) {
+                    const float wf = buf[XB + ((ae * NCO + mt) * 16 + m16) * CKP + 4 * ks + q];
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) acc[ae][mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xf[pt], acc[ae][mt][pt], 0, 0, 0);
+                }
+        }
+        if (c + 1 < nchunks) {
+            commit(lds + ((c + 1) & 1) * BUF);
+            if (c + 2 < nchunks) issue(c + 2);
+        }
+        lds_barrier();
+    }
+    // epilogue: lane (m16, q) holds channels co0 + 16 mt + 4 q .. + 3 of input pixel p0 + 32 wave + 16 pt + m16, all four parities
+    f32x4 bias[NCO], bs[NCO], bq[NCO];
+#pragma unroll
+    for (int mt = 0; mt < NCO; ++mt) {
+        bias[mt] = *reinterpret_cast<const f32x4*>(p.bias + co0 + 16 * mt + 4 * q);
+        bs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bq[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int px = p0 + 32 * wave + 16 * pt + m16;
+        if (px >= p.npix) continue;
+#pragma unroll
+        for (int ae = 0; ae < 4; ++ae) {
+            float* op = p.out + tc_outpix(px, ae >> 1, ae & 1, p.H, p.W) * p.cout + co0 + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NCO; ++mt) {
+                const f32x4 v = acc[ae][mt][pt] + bias[mt];
+                *reinterpret_cast<f32x4*>(op + 16 * mt) = v;
+                bs[mt] += v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bq[mt][i] = fmaf(v[i], v[i], bq[mt][i]);
+            }
+        }
+    }
+    if (p.bnf.tab) {        // batch statistics for the BatchNorm behind the transposed conv: a bucket row per pixel block
+#pragma unroll
+        for (int mt = 0; mt < NCO; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s1 = row16_sum(bs[mt][i]), s2 = row16_sum(bq[mt][i]);
+                if (m16 == 0) { red[wave * (2 * COT) + 16 * mt + 4 * q + i] = s1; red[wave * (2 * COT) + COT + 16 * mt + 4 * q + i] = s2; }
+            }
+        __syncthreads();
+        if (tid < 2 * COT) {
+            const float sum = (red[tid] + red[2 * COT + tid]) + (red[4 * COT + tid] + red[6 * COT + tid]);
+            const int half = tid >= COT, c = half ? tid - COT : tid;
+            atomicAdd(bn_bucket(p.bnf, (int)blockIdx.x) + half * p.cout + co0 + c, (double)sum);
+        }
+        bn_self_fold(p.bnf, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+    }
+}
+
 // data gradient: din[p][ci] = sum_{a,e,co} dout[out(p,a,e)][co] * W[a][e][co][ci]   (N = ci tile, K = 4 x Cout)
 template <int NN>
 __global__ __launch_bounds__(256) void k_ig_tconv_dgrad(TcArgs p) {
@@ -3190,6 +3309,17 @@ bool ig_tconv_fwd(Model* m, int B, Op& o, double bytes, double flops, Op* bn_nex
         return true;
     }
     const int nn = pick_nn(a.cout);
+    static const bool gen1f = getenv("DNNCA_TCONV_FWD1") != nullptr;          // A/B: the first-generation kernel
+    if (!gen1f && !o.inA.d.h && !o.out.d.h && a.cin % ig::CK == 0 && (double)a.npix * 4.0 * a.cout < 2.0e9) {
+        // batch statistics of the BatchNorm behind it ride in the epilogue
+        const bool stats = bn_next && !dense_switches().no_bn_fusion && bn_self_fold_args(m, *bn_next, B, &a.bnf);
+        const dim3 g2((a.npix + 127) / 128, a.cout / (16 * nn));
+        m->set_variant("2n%d%s", nn, stats ? "s" : "");
+        if (nn == 4) LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd2<4>), g2, dim3(256), 0, m->stream, a));
+        else if (nn == 2) LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd2<2>), g2, dim3(256), 0, m->stream, a));
+        else LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd2<1>), g2, dim3(256), 0, m->stream, a));
+        return true;
+    }
     dim3 grid((a.npix + 127) / 128, a.cout / (16 * nn), 4);
     m->set_variant("n%d", nn);
     if (nn == 4) LAUNCH(m, "ig_tconv_fwd", bytes, flops, hipLaunchKernelGGL((ig::k_ig_tconv_fwd<4>), grid, dim3(256), 0, m->stream, a));
