@@ -1493,6 +1493,12 @@ constexpr unsigned OOB = 0x80000000u;               // beyond every tensor here:
 // k_igb_tconv_fwd2: the stores alone were half of a full-resolution launch).  otile: NW x [8 pixels][OTS]; wave w's first 512 bytes
 // double as its slot of the statistics fold.
 constexpr int OTS = 64 + 8;             // bf16 per pixel of the epilogue tile (144 B: the 8-byte writes of a half spread over the banks)
+// Where a unit's epilogue time goes (tools/ig_stamps.py, 64 -> 64 channels at 512 x 512: 10.9 k of the unit's 24.7 k ticks): the
+// four rows 1.65 k each -- VECTOR-ALU work, ~170 instructions per row for a lane's 16 values (bias, activation, rounding, the two
+// statistics) with two waves per SIMD in the epilogue at once --, the DPP sums 1.4 k, then a block barrier (1.5 k) and the bucket adds
+// (1 k).  Tried: the bias through LDS (nothing); the block's statistics in one LDS slot by LDS atomics until the kernel ends (the
+// barrier and the bucket adds gone, -2 % per launch -- and the float sums then depend on the order the waves arrive in, which under
+// dtype bf16 moves gradients by 1e-2 from run to run: not kept).
 template <int MODE, int NW>
 __device__ __forceinline__ void epilogue_cm(const ConvArgs& p, const f32x4 (&acc)[4][4], int b, int y0, int x0, int co0, int tile, bf16_t* otile) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
@@ -1511,9 +1517,12 @@ __device__ __forceinline__ void epilogue_cm(const ConvArgs& p, const f32x4 (&acc
     const int x = x0 + m16;
     const bool okx = x < p.W;
     const bool half_out = MODE == 0 ? p.dst_half != 0 : (p.dsth[which] != 0 && !p.acc[which]);      // block-uniform: through the LDS tile
+    const bool act_max = p.alpha >= 0.f && p.alpha <= 1.f;
+    IGSTAMP(48, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int y = y0 + 4 * wave + r;
+        IGSTAMP(48, 1 + r);
         if (y >= p.H) continue;                 // wave-uniform
         // element offset in 32 bits (the launcher checks that every destination has fewer than 2^32 elements)
         const unsigned orow = (unsigned)(b * p.H + y) * (unsigned)p.W;
@@ -1523,16 +1532,18 @@ __device__ __forceinline__ void epilogue_cm(const ConvArgs& p, const f32x4 (&acc
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 t = acc[r][j] + bias[j];
-                if (MODE == 0 && p.alpha >= 0.f) {
+                if (MODE == 0 && act_max) {          // 0 <= alpha <= 1: act(t) = max(t, alpha t), two instructions instead of three
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = fmaxf(t[i], p.alpha * t[i]);
+                } else if (MODE == 0 && p.alpha >= 0.f) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) t[i] = t[i] > 0.f ? t[i] : p.alpha * t[i];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { th[j][i] = (hbf16)t[i]; t[i] = (float)th[j][i]; }      // the statistics are those of the stored values
-                if (bn_on && okx) {
+                if (bn_on && okx) {          // (vector forms: packed fp32 instructions)
                     bs[j] += t;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bq[j][i] = fmaf(t[i], t[i], bq[j][i]);
+                    bq[j] += t * t;
                 }
             }
 #pragma unroll
@@ -1594,6 +1605,7 @@ __device__ __forceinline__ void epilogue_cm(const ConvArgs& p, const f32x4 (&acc
             }
         }
     }
+    IGSTAMP(48, 5);
     if (bn_on) {        // this unit's sums go to bucket row tile % R: [2 cw], first half sums, second half sums of squares
         float* red = reinterpret_cast<float*>(ot);          // the wave's 128-float slot (its tile is free: DS operations execute in order)
 #pragma unroll
@@ -1603,7 +1615,9 @@ __device__ __forceinline__ void epilogue_cm(const ConvArgs& p, const f32x4 (&acc
                 const float s1 = ig::row16_sum(bs[j][i]), s2 = ig::row16_sum(bq[j][i]);
                 if (m16 == 0) { red[16 * j + 4 * q + i] = s1; red[64 + 16 * j + 4 * q + i] = s2; }
             }
+        IGSTAMP(48, 6);
         lds_barrier();
+        IGSTAMP(48, 7);
         if (tid < 128) {
             float a = 0.f;
 #pragma unroll

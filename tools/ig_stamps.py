@@ -34,3 +34,6 @@ for i, nme in enumerate(names):
 print('%-26s' % 'item total', ' '.join('%6d' % (t[it, 6] - t[it, 0]) for it in range(min(nchunks, 12))))
 print('%-26s' % 'gap to next item', ' '.join('%6d' % (t[it + 1, 0] - t[it, 6]) for it in range(min(nchunks, 12) - 1)))
 print('epilogue of unit 0: %d ticks' % (t[nchunks - 1, 7] - t[nchunks - 1, 6]))
+e = t[48]
+print('inside the epilogue (first unit; ticks): to row 0 %d, rows %s, statistics sums + LDS %d, barrier %d; then the bucket adds' % (
+    e[1] - e[0], ' '.join(str(int(e[2 + r] - e[1 + r])) for r in range(4)), e[6] - e[5], e[7] - e[6]))
