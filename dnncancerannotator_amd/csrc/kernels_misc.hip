@@ -932,7 +932,8 @@ bool bn_self_fold_args(Model* m, Op& bn, int B, BnSelfFold* f) {
 static unsigned bn_blocks(size_t npix, int C) {
     const size_t PL = 256 / (C / 4);
     size_t b = (npix + PL * 32 - 1) / (PL * 32);
-    if (b > 512) b = 512;
+    static const size_t cap = getenv("DNNCA_BN_BLOCKS") ? (size_t)atoi(getenv("DNNCA_BN_BLOCKS")) : 512;          // tuning aid
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (unsigned)b;
 }
