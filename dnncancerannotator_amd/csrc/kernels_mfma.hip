@@ -903,7 +903,7 @@ __global__ __launch_bounds__(NT, (VW && NSRC == 1) ? 4 : 1) void k_pgbwd(BwdArgs
         if constexpr (TCF) {
             // ---- transposed conv backward on the data-gradient waves: lane = one input pixel (pr, pc) of this wave's column block; its
             // 2 x 2 output pixels' gradients are in the LDS tile this wave has just written (DS operations of one wave execute in order)
-            if (wave < NWD && !(DBG_FLAGS(p) & 1)) {
+            if (wave < NWD && !(DBG_FLAGS(p) & 5)) {          // (tuning builds: DNNCA_DBG bit 2 skips this part alone)
                 __builtin_amdgcn_wave_barrier();
                 const int pr = lane >> 4, pc = lane & 15;
                 const float* dt = reinterpret_cast<const float*>(dta4);
