@@ -516,6 +516,26 @@ def test_exact_fp32_conv_kernels_behind_the_switch(gpu):
     Hp.record_oracle_plan(set(o['plan']) | set(k.split('#')[0] for k in o['plan']), 'test_exact_fp32_conv_kernels_behind_the_switch')
 
 
+def test_first_generation_transposed_conv_forward_behind_the_switch(gpu):
+    """DNNCA_TCONV_FWD1=1 takes the Conv2DTranspose forward back to the first-generation kernels (one block per output parity, no
+    fused statistics: ig::k_ig_tconv_fwd -- still the fallback for outputs beyond 2^31 elements): a BatchNorm decoder level in a child
+    process against the float64 oracle, the same bound as the default path."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    case = dict(arch='unet', C=1, opts=dict(n_filters_first=32, n_downsample=2, bn=True), B=2, H=32, W=48, alpha=0.99, seed=121)
+    r = subprocess.run([sys.executable, os.path.join(here, 'oracle_case.py'), json.dumps(case)], env=dict(os.environ, DNNCA_TCONV_FWD1='1'),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    o = json.loads(r.stdout.strip().splitlines()[-1])
+    assert abs(o['loss'] - o['loss_ref']) <= 1e-4 * max(1.0, abs(o['loss_ref']))
+    bad = {n: e for n, e in o['errs'].items() if not e <= 1e-4 + o['floors'][n]}
+    assert not bad, bad
+    assert any(k.startswith('ig_tconv_fwd#n') for k in o['plan']) and 'bn_stats' in set(k.split('#')[0] for k in o['plan']), o['plan']
+    Hp.record_oracle_plan(set(o['plan']) | set(k.split('#')[0] for k in o['plan']), 'test_first_generation_transposed_conv_forward_behind_the_switch')
+
+
 def _per_tensor_cosine(spec, g, gref):
     out = {}
     for n, sl in Hp.tensor_slices(spec):
