@@ -670,19 +670,35 @@ __global__ __launch_bounds__(256) void k_bn_stats_fast(size_t npix, const float*
     bn_self_fold(f, gridDim.x, blockIdx.x);
 }
 
+// One thread = kBnU four-channel groups 256 elements apart (C / 4 divides 256: the same channel group every time, its coefficients are
+// loaded once): kBnU loads in flight per thread.  With ONE element per thread a CU had 16 KB of loads in flight (32 waves x 8-byte
+// loads of bf16-stored tensors) -- the passes ran at what that buys against the memory latency, 4.5 TB/s, not at what HBM delivers.
+// (f32 tensors, 16-byte loads: one element per thread as before -- four were 2 % slower on mulmo_unet.)
+constexpr int bn_u(bool any_half) { return any_half ? 4 : 1; }
 template <bool YH, bool XH>      // YH / XH: y / x is stored as bf16
 __global__ __launch_bounds__(256) void k_bn_apply_fast(size_t n4, const float* __restrict__ x, float* __restrict__ y, int C,
                                                        int yps, const float* __restrict__ coef) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const int G = C / 4, cq = (int)(i % G);
-    const size_t p = i / G;
-    const float4 v = ld4<XH>(x, 4 * i);
+    constexpr int kBnU = bn_u(YH || XH);
+    const size_t i0 = (size_t)blockIdx.x * (256 * kBnU) + threadIdx.x;
+    if (i0 >= n4) return;
+    const int G = C / 4, cq = (int)(i0 % G);
+    float4 v[kBnU];
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+        const size_t i = i0 + 256 * u;
+        v[u] = ld4<XH>(x, 4 * (i < n4 ? i : i0));
+    }
     const float4 sc = *reinterpret_cast<const float4*>(coef + 4 * cq), sh = *reinterpret_cast<const float4*>(coef + C + 4 * cq);
-    float4 o;
-    o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
-    if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + p * yps + 4 * cq) = to_bf16x4(o);
-    else *reinterpret_cast<float4*>(y + p * yps + 4 * cq) = o;
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+        const size_t i = i0 + 256 * u;
+        if (i >= n4) break;
+        const size_t p = i / G;
+        float4 o;
+        o.x = fmaf(v[u].x, sc.x, sh.x); o.y = fmaf(v[u].y, sc.y, sh.y); o.z = fmaf(v[u].z, sc.z, sh.z); o.w = fmaf(v[u].w, sc.w, sh.w);
+        if (YH) *reinterpret_cast<hbf16x4*>(reinterpret_cast<hbf16*>(y) + p * yps + 4 * cq) = to_bf16x4(o);
+        else *reinterpret_cast<float4*>(y + p * yps + 4 * cq) = o;
+    }
 }
 
 // BatchNorm apply + the MaxPool2D([2,2], 2) that follows it (components.py:54,59): one thread owns a 4-channel group of a 2 x 2
@@ -823,7 +839,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_fast(size_t npix, const f
     const int G = C / 4, cq = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
     const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
     float sg[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
-    constexpr int U = 4;            // 8 loads in flight per thread
+    constexpr int U = 4;            // 8 loads in flight per thread (16 for the 8-byte loads of bf16-stored tensors: +4 % per launch, measured)
     const size_t chunk = (size_t)U * PL, nfull = npix / chunk;
     // chunks back to front: whichever kernel produced dy wrote it front to back, its tail is what the Infinity Cache still holds;
     // the apply pass that follows walks front to back and finds this pass's last reads there
@@ -874,31 +890,42 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_fast(size_t n4, const floa
                                                            const float* __restrict__ coef, const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            float inv_n, int mask, float alpha, PoolGrad pg) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const int G = C / 4, cq = (int)(i % G);
-    const size_t p = i / G;
-    const float4 v = ld4<XH>(x, 4 * i);
-    const float4 d = with_pool_grad<PG, GH>(PG == 1 ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4<GH>(dy, p * dps + 4 * cq), pg, (unsigned)p, cq, G);
+    // kBnU elements per thread, 256 apart (see k_bn_apply_fast): the same channel group, all loads in flight together
+    constexpr int kBnU = bn_u(DH || XH || GH);
+    const size_t i0 = (size_t)blockIdx.x * (256 * kBnU) + threadIdx.x;
+    if (i0 >= n4) return;
+    const int G = C / 4, cq = (int)(i0 % G);
+    float4 vv[kBnU], dd[kBnU], tt[kBnU];
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+        const size_t i = i0 + 256 * u < n4 ? i0 + 256 * u : i0, p = i / G;
+        vv[u] = ld4<XH>(x, 4 * i);
+        dd[u] = PG == 1 ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4<GH>(dy, p * dps + 4 * cq);
+        if (!DH && acc) tt[u] = reinterpret_cast<const float4*>(dx)[i];
+    }
     const float4 mean = *reinterpret_cast<const float4*>(coef + 2 * C + 4 * cq), inv = *reinterpret_cast<const float4*>(coef + 3 * C + 4 * cq);
     const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * cq);
     const float4 dg = *reinterpret_cast<const float4*>(dgamma + 4 * cq), db = *reinterpret_cast<const float4*>(dbeta + 4 * cq);
-    float4 r;
-    r.x = g.x * inv.x * (d.x - inv_n * (db.x + (v.x - mean.x) * inv.x * dg.x));
-    r.y = g.y * inv.y * (d.y - inv_n * (db.y + (v.y - mean.y) * inv.y * dg.y));
-    r.z = g.z * inv.z * (d.z - inv_n * (db.z + (v.z - mean.z) * inv.z * dg.z));
-    r.w = g.w * inv.w * (d.w - inv_n * (db.w + (v.w - mean.w) * inv.w * dg.w));
-    float4* o = reinterpret_cast<float4*>(dx) + i;
-    if (!DH && acc) {
-        const float4 t = *o;
-        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+        const size_t i = i0 + 256 * u;
+        if (i >= n4) break;
+        const size_t p = i / G;
+        const float4 v = vv[u];
+        const float4 d = with_pool_grad<PG, GH>(dd[u], pg, (unsigned)p, cq, G);
+        float4 r;
+        r.x = g.x * inv.x * (d.x - inv_n * (db.x + (v.x - mean.x) * inv.x * dg.x));
+        r.y = g.y * inv.y * (d.y - inv_n * (db.y + (v.y - mean.y) * inv.y * dg.y));
+        r.z = g.z * inv.z * (d.z - inv_n * (db.z + (v.z - mean.z) * inv.z * dg.z));
+        r.w = g.w * inv.w * (d.w - inv_n * (db.w + (v.w - mean.w) * inv.w * dg.w));
+        if (!DH && acc) { r.x += tt[u].x; r.y += tt[u].y; r.z += tt[u].z; r.w += tt[u].w; }
+        if (mask) {      // x is the activated conv output: hand the producing conv its pre-activation gradient directly
+            r.x *= v.x > 0.f ? 1.0f : alpha; r.y *= v.y > 0.f ? 1.0f : alpha;
+            r.z *= v.z > 0.f ? 1.0f : alpha; r.w *= v.w > 0.f ? 1.0f : alpha;
+        }
+        if (DH) reinterpret_cast<hbf16x4*>(dx)[i] = to_bf16x4(r);
+        else reinterpret_cast<float4*>(dx)[i] = r;
     }
-    if (mask) {      // x is the activated conv output: hand the producing conv its pre-activation gradient directly
-        r.x *= v.x > 0.f ? 1.0f : alpha; r.y *= v.y > 0.f ? 1.0f : alpha;
-        r.z *= v.z > 0.f ? 1.0f : alpha; r.w *= v.w > 0.f ? 1.0f : alpha;
-    }
-    if (DH) reinterpret_cast<hbf16x4*>(dx)[i] = to_bf16x4(r);
-    else *o = r;
 }
 
 static bool bn_table(Model* m) {          // arrives zeroed, stays zeroed between uses
@@ -1004,7 +1031,8 @@ bool fast_bn_fwd(Model* m, int B, Op& o, bool training, float momentum, float ep
 #undef BNPOOL
         return true;
     }
-    const dim3 grid((unsigned)((n4 + 255) / 256));
+    const int bu = bn_u(o.inA.d.h || o.out.d.h);
+    const dim3 grid((unsigned)((n4 + 256 * bu - 1) / (256 * bu)));
     const double ab = tb * ((o.inA.d.h ? 0.5 : 1.0) + (o.out.d.h ? 0.5 : 1.0));
 #define BNAPPLY(YHv, XHv) LAUNCH(m, "bn_apply", ab, tb / 2,                                                                  \
         hipLaunchKernelGGL((k_bn_apply_fast<YHv, XHv>), grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.d.p, C, o.out.d.ps, o.coef))
@@ -1098,7 +1126,8 @@ bool fast_bn_bwd(Model* m, int B, Op& o) {
     else { if (gh) BNRED(false, true, 0); else BNRED(false, false, 0); }
 #undef BNRED
     const size_t n4 = npix * (C / 4);
-    const dim3 grid((unsigned)((n4 + 255) / 256));
+    const int bu = bn_u(!pgm && (dh || xh || gh));          // (the pooled-gradient variants run on f32 tensors)
+    const dim3 grid((unsigned)((n4 + 256 * bu - 1) / (256 * bu)));
     m->set_variant("p%d", pgm);
 #define BNBWD(DHv, XHv, GHv, PGv) LAUNCH(m, "bn_bwd_apply", rb + tb * (DHv ? 0.5 : 1.0), 2 * tb,                             \
         hipLaunchKernelGGL((k_bn_bwd_apply_fast<DHv, XHv, GHv, PGv>), grid, dim3(256), 0, m->stream, n4, o.inA.d.p, o.out.g.p, \
