@@ -2427,11 +2427,18 @@ __global__ __launch_bounds__(512, 2) void k_igb_tconv_fwd2(TcArgs p, const bf16_
 }
 
 // data gradient: din[p][ci] = sum_{ae,co} dout[out(p,ae)][co] * W[ae][co][ci]; block = 128 pixels x 64 input channels,
-// K = 4 x Cout in chunks of 32; w16 = [ae][ci][co] (K = co contiguous)
-template <bool G16>      // G16: dout is stored as bf16
+// K = 4 x Cout in chunks of KC; w16 = [ae][ci][co] (K = co contiguous).  KC = 64 with bf16-stored dout (round 4): 16-byte loads
+// of eight channels and half as many chunks -- a block's K loop is a chain of memory round trips (one chunk in flight), and
+// with 32-channel chunks of 8-byte loads a block had 12 KB in flight.
+template <bool G16, int KC>      // G16: dout is stored as bf16
 __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16_t* __restrict__ w16) {
-    __shared__ __attribute__((aligned(16))) bf16_t a_lds[128 * RS];
-    __shared__ __attribute__((aligned(16))) bf16_t b_lds[64 * RS];
+    static_assert(KC == 32 || (KC == 64 && G16), "64-channel chunks: bf16-stored dout");
+    constexpr int RSK = KC + 8;                      // LDS row stride (bf16)
+    constexpr int AW = G16 ? KC / 16 : KC / 8;       // staging words per thread: 16 bytes (eight bf16 / four f32 channels) each
+    constexpr int PPW = G16 ? KC / 8 : KC / 4;       // words per pixel
+    constexpr int BW = KC / 32;                      // 16-byte kernel words per thread: 64 rows x KC / 8
+    __shared__ __attribute__((aligned(16))) bf16_t a_lds[128 * RSK];
+    __shared__ __attribute__((aligned(16))) bf16_t b_lds[64 * RSK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
     const int p0 = blockIdx.x * 128, n0 = blockIdx.y * 64;
     f32x4 acc[2][4];
@@ -2439,49 +2446,57 @@ __global__ __launch_bounds__(256, 2) void k_igb_tconv_dgrad(TcArgs p, const bf16
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    using AR = std::conditional_t<G16, bf16x4, float4>;
-    AR ar[4];
-    u32x4 br;
+    u32x4 ar[AW], br[BW];
     auto issue = [&](int kc) {
         const int ae = kc / p.cout, cc = kc - ae * p.cout;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
+        for (int u = 0; u < AW; ++u) {
+            const int i = tid + 256 * u, px = i / PPW, part = i % PPW;
             const bool ok = p0 + px < p.npix;
-            const size_t o = ok ? tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + cc + 4 * c4 : 0;
-            if constexpr (G16) {
-                ar[u] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                if (ok) ar[u] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.dout) + o);
-            } else {
-                ar[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) ar[u] = *reinterpret_cast<const float4*>(p.dout + o);
-            }
+            const size_t o = ok ? tc_outpix(p0 + px, ae >> 1, ae & 1, p.H, p.W) * p.cout + cc + (G16 ? 8 : 4) * part : 0;
+            ar[u] = u32x4{0u, 0u, 0u, 0u};
+            if (ok) ar[u] = G16 ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.dout) + o) : *reinterpret_cast<const u32x4*>(p.dout + o);
         }
-        br = *reinterpret_cast<const u32x4*>(w16 + ((size_t)ae * p.cin + n0 + (tid >> 2)) * p.cout + cc + 8 * (tid & 3));
+#pragma unroll
+        for (int u = 0; u < BW; ++u) {
+            const int i = tid + 256 * u, r = i / (KC / 8), part = i % (KC / 8);
+            br[u] = *reinterpret_cast<const u32x4*>(w16 + ((size_t)ae * p.cin + n0 + r) * p.cout + cc + 8 * part);
+        }
     };
     issue(0);
 #pragma unroll 1
-    for (int kc = 0; kc < 4 * p.cout; kc += CK) {
+    for (int kc = 0; kc < 4 * p.cout; kc += KC) {
         lds_barrier();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + 256 * u, px = i >> 3, c4 = i & 7;
-            bf16x4 h;
-            if constexpr (G16) h = ar[u];
-            else { h[0] = (bf16_t)ar[u].x; h[1] = (bf16_t)ar[u].y; h[2] = (bf16_t)ar[u].z; h[3] = (bf16_t)ar[u].w; }
-            *reinterpret_cast<bf16x4*>(a_lds + px * RS + 4 * c4) = h;
+        for (int u = 0; u < AW; ++u) {
+            const int i = tid + 256 * u, px = i / PPW, part = i % PPW;
+            if constexpr (G16) {
+                *reinterpret_cast<u32x4*>(a_lds + px * RSK + 8 * part) = ar[u];
+            } else {
+                const f32x4 f = __builtin_bit_cast(f32x4, ar[u]);
+                bf16x4 h;
+                h[0] = (bf16_t)f[0]; h[1] = (bf16_t)f[1]; h[2] = (bf16_t)f[2]; h[3] = (bf16_t)f[3];
+                *reinterpret_cast<bf16x4*>(a_lds + px * RSK + 4 * part) = h;
+            }
         }
-        *reinterpret_cast<u32x4*>(b_lds + (tid >> 2) * RS + 8 * (tid & 3)) = br;
-        if (kc + CK < 4 * p.cout) issue(kc + CK);
+#pragma unroll
+        for (int u = 0; u < BW; ++u) {
+            const int i = tid + 256 * u, r = i / (KC / 8), part = i % (KC / 8);
+            *reinterpret_cast<u32x4*>(b_lds + r * RSK + 8 * part) = br[u];
+        }
+        if (kc + KC < 4 * p.cout) issue(kc + KC);
         lds_barrier();
-        bf16x8 bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(b_lds + (16 * j + m16) * RS + 8 * q);
+        for (int ks = 0; ks < KC / 32; ++ks) {
+            bf16x8 bv[4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(a_lds + (32 * wave + 16 * r + m16) * RS + 8 * q);
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(b_lds + (16 * j + m16) * RSK + 32 * ks + 8 * q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[r][j], 0, 0, 0);
+            for (int r = 0; r < 2; ++r) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(a_lds + (32 * wave + 16 * r + m16) * RSK + 32 * ks + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[r][j], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -3361,11 +3376,15 @@ bool ig_tconv_bwd(Model* m, int B, Op& o, double out_bytes, double in_bytes, dou
         else { if (gh) TW64(false, true); else TW64(false, false); }
         if (side) m->wg_side_end(main_stream);
 #undef TW64
-        m->set_variant("g%d", (int)gh);
-        if (gh)
-            LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_dgrad<true>, gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
+        static const bool k32 = getenv("DNNCA_TCONV_DGRAD_K32") != nullptr;          // A/B: 32-channel chunks
+        const bool k64 = gh && !k32 && a.cout % 64 == 0;
+        m->set_variant("g%d%s", (int)gh, k64 ? "k64" : "");
+        if (k64)
+            LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((igb::k_igb_tconv_dgrad<true, 64>), gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
+        else if (gh)
+            LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((igb::k_igb_tconv_dgrad<true, 32>), gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
         else
-            LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL(igb::k_igb_tconv_dgrad<false>, gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
+            LAUNCH(m, "igb_tconv_dgrad", out_bytes + in_bytes, flops, hipLaunchKernelGGL((igb::k_igb_tconv_dgrad<false, 32>), gd, dim3(256), 0, m->stream, a, pl.wd + o.w_off));
         return true;
     }
     hipStream_t main_stream = m->stream;
