@@ -954,63 +954,94 @@ __global__ __launch_bounds__(256, 2) void k_ig_tconv_fwd2(TcArgs p) {
     }
 }
 
-// data gradient: din[p][ci] = sum_{a,e,co} dout[out(p,a,e)][co] * W[a][e][co][ci]   (N = ci tile, K = 4 x Cout)
+// data gradient: din[p][ci] = sum_{a,e,co} dout[out(p,a,e)][co] * W[a][e][co][ci]   (N = ci tile, K = 4 x Cout).
+// Round 4: two LDS buffers with register prefetch (chunk c + 2's loads fly during chunk c's MFMAs: one barrier per chunk; the first
+// version loaded, waited, multiplied, chunk after chunk) and MFMAs channel-major (rows = input channels, columns = pixels): a lane
+// holds four consecutive channels of a pixel -- 16-byte loads / stores in the epilogue.  Same fp32 MFMA chain per value (K ascending).
 template <int NN>
 __global__ __launch_bounds__(256) void k_ig_tconv_dgrad(TcArgs p) {
     constexpr int NT = 16 * NN, BSTR = NT + 16;
-    __shared__ float a_lds[128 * CKP];
-    __shared__ float b_lds[CK * BSTR];
+    constexpr int AB = 128 * CKP, BB = CK * BSTR, BUF = AB + BB;
+    constexpr int BW = CK * (NT / 4) / 256 > 0 ? CK * (NT / 4) / 256 : 1;          // kernel float4 words per thread (NT = 64: one)
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, q = lane >> 4;
     const int p0 = blockIdx.x * 128, n0 = blockIdx.y * NT;
+    const int nchunks = 4 * p.cout / CK;
     f32x4 acc[2][NN];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int j = 0; j < NN; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ar[2], br[BW];
+    auto issue = [&](int c) {
+        const int kc = c * CK, ae = kc / p.cout, cc = kc - ae * p.cout, a = ae >> 1, e = ae & 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, px = i >> 2, c4 = i & 3;
+            ar[u] = p0 + px < p.npix ? *reinterpret_cast<const f32x4*>(p.dout + tc_outpix(p0 + px, a, e, p.H, p.W) * p.cout + cc + 4 * c4)
+                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < BW; ++u) {
+            const int i = tid + 256 * u, n4 = i % (NT / 4), k = i / (NT / 4);
+            if (k < CK) br[u] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)ae * p.cout + cc + k) * p.cin + n0 + 4 * n4);
+        }
+    };
+    auto commit = [&](float* buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, px = i >> 2, c4 = i & 3;
+            *reinterpret_cast<f32x4*>(buf + px * CKP + 4 * c4) = ar[u];
+        }
+#pragma unroll
+        for (int u = 0; u < BW; ++u) {
+            const int i = tid + 256 * u, n4 = i % (NT / 4), k = i / (NT / 4);
+            if (k < CK) *reinterpret_cast<f32x4*>(buf + AB + k * BSTR + 4 * n4) = br[u];
+        }
+    };
+    issue(0);
+    commit(lds);
+    if (nchunks > 1) issue(1);
+    lds_barrier();
 #pragma unroll 1
-    for (int kc = 0; kc < 4 * p.cout; kc += CK) {
-        const int ae = kc / p.cout, cc = kc - ae * p.cout, a = ae >> 1, e = ae & 1;
-        lds_barrier();
-        for (int i = tid; i < 128 * 4; i += 256) {
-            const int px = i >> 2, c4 = i & 3;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + px < p.npix) v = *reinterpret_cast<const float4*>(p.dout + tc_outpix(p0 + px, a, e, p.H, p.W) * p.cout + cc + 4 * c4);
-            *reinterpret_cast<float4*>(a_lds + px * CKP + 4 * c4) = v;
-        }
-        for (int i = tid; i < CK * (NT / 4); i += 256) {
-            const int n4 = i % (NT / 4), k = i / (NT / 4);
-            const float4 v = *reinterpret_cast<const float4*>(p.w + ((size_t)ae * p.cout + cc + k) * p.cin + n0 + 4 * n4);
-            *reinterpret_cast<float4*>(b_lds + k * BSTR + 4 * n4) = v;
-        }
-        lds_barrier();
+    for (int c = 0; c < nchunks; ++c) {
+        const float* buf = lds + (c & 1) * BUF;
 #pragma unroll
         for (int k4 = 0; k4 < CK / 4; ++k4) {
             float bv[NN];
 #pragma unroll
-            for (int j = 0; j < NN; ++j) bv[j] = b_lds[(4 * k4 + q) * BSTR + 16 * j + m16];
+            for (int j = 0; j < NN; ++j) bv[j] = buf[AB + (4 * k4 + q) * BSTR + 16 * j + m16];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const float av = a_lds[(32 * wave + 16 * r + m16) * CKP + 4 * k4 + q];
+                const float av = buf[(32 * wave + 16 * r + m16) * CKP + 4 * k4 + q];
 #pragma unroll
-                for (int j = 0; j < NN; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[r][j], 0, 0, 0);
+                for (int j = 0; j < NN; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av, acc[r][j], 0, 0, 0);      // rows = channels, columns = pixels
             }
+        }
+        if (c + 1 < nchunks) {
+            commit(lds + ((c + 1) & 1) * BUF);
+            if (c + 2 < nchunks) issue(c + 2);
+        }
+        lds_barrier();
+    }
+    // lane (m16, q): channels n0 + 16 j + 4 q .. + 3 of pixel p0 + 32 wave + 16 r + m16
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int px = p0 + 32 * wave + 16 * r + m16;
+        if (px >= p.npix) continue;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            const size_t o = (size_t)px * p.cin + n0 + 16 * j + 4 * q;
+            f32x4 v = acc[r][j];
+            if (p.acc) v += *reinterpret_cast<const f32x4*>(p.din + o);
+            if (p.mask) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= mk[i] > 0.f ? 1.0f : p.alpha;
+            }
+            *reinterpret_cast<f32x4*>(p.din + o) = v;
         }
     }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = p0 + 32 * wave + 16 * r + 4 * q + i;
-            if (px >= p.npix) continue;
-#pragma unroll
-            for (int j = 0; j < NN; ++j) {
-                const size_t o = (size_t)px * p.cin + n0 + 16 * j + m16;
-                float v = acc[r][j][i];
-                if (p.acc) v += p.din[o];
-                if (p.mask) v *= p.mask[o] > 0.f ? 1.0f : p.alpha;
-                p.din[o] = v;
-            }
-        }
 }
 
 // weight gradient: dW[a][e][co][ci] = sum_p dout[out(p,a,e)][co] * in[p][ci]   (M = 16 co, N = ci tile, K = pixels)
